@@ -1,0 +1,450 @@
+// Per-candidate kernels of the acquisition path and the C entry points that chain them:
+//
+//   gram -> GEMM (A = Ks L^-T) -> k_stage2 (mu, Sigma, SDP, Z = M11 A) -> GEMM (W = Z L^-1)
+//        -> k_grad (closed-form d<Omega,M>/dX)
+//
+// Replaces OEI.acquisition / OEI.omega / predict_f of the reference (oei.py:19-39, 79-103) for B
+// candidate batches at once.  The gradient is the closed form of what the reference gets from
+// tf.gradients with M held constant (oei.py:66-77):
+//   d value/d x_a = J_a^T (p_a alpha - 2 W[:,a]) + 2 sum_{b != a} M11_ab dk(x_a,x_b)/dx_a,
+//   J_a = dk(X, x_a)/dx_a,  W = K^-1 k(X,X*) M11,  p = d value/d mu.
+#include "oei_sdp.cuh"
+
+#define CH 64            // training-point chunk staged in LDS
+#define ITEMS_MAX 10     // per-thread accumulators in the chunked reductions
+
+// Posterior moments of candidate b into LDS: w.S = Sigma + noise I (full, symmetric), mu[].
+// xq [q][d] must already be in LDS.  Ac is a [q][CH+1] staging buffer, vc a [CH] one.
+template <int T>
+__device__ void posterior_moments(const SdpWork& w, const KernParams& kp, double noise, int n,
+                                  int npad, const double* __restrict__ Arows,
+                                  const double* __restrict__ v, const double* xq, double* mu,
+                                  double* Ac, double* vc) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD, d = kp.d;
+    const int npair = q * (q + 1) / 2, nitems = npair + q;
+    double acc[ITEMS_MAX];
+    int ii[ITEMS_MAX], jj[ITEMS_MAX];
+#pragma unroll
+    for (int u = 0; u < ITEMS_MAX; ++u) {
+        acc[u] = 0.0;
+        const int e = tid + u * T;
+        int i = 0, j = -1;
+        if (e < npair) {
+            i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            j = e - i * (i + 1) / 2;
+        } else if (e < nitems) {
+            i = e - npair; j = -1;
+        }
+        ii[u] = i; jj[u] = j;
+    }
+    const int nchunks = (n + CH - 1) / CH;
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        for (int e = tid; e < q * CH; e += T) {
+            const int a = e / CH, k = e - a * CH;
+            Ac[a * (CH + 1) + k] = Arows[(size_t)a * npad + c * CH + k];
+        }
+        for (int k = tid; k < CH; k += T) vc[k] = v[c * CH + k];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ITEMS_MAX; ++u) {
+            if (u * T >= nitems) break;                  // uniform; idle lanes redo item 0
+            const double* ra = Ac + ii[u] * (CH + 1);
+            const double* rb = (jj[u] >= 0) ? Ac + jj[u] * (CH + 1) : vc;
+            double s = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < CH; ++k) s += ra[k] * rb[k];
+            acc[u] += s;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ITEMS_MAX; ++u) {
+        const int e = tid + u * T;
+        if (e >= nitems) break;
+        const int i = ii[u], j = jj[u];
+        if (j < 0) { mu[i] = acc[u]; continue; }
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[i * d + l] - xq[j * d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        const double val = kp.variance * k0 - acc[u] + (i == j ? noise : 0.0);
+        w.S[i * LD + j] = val;
+        w.S[j * LD + i] = val;
+    }
+    __syncthreads();
+}
+
+__host__ __device__ inline size_t acq_extra_doubles(int q, int d) {
+    // mu[q+2] + xq[q*d] + Ac[q*(CH+1)] + vc[CH]
+    return (size_t)(q + 2) + (size_t)q * d + (size_t)q * (CH + 1) + CH;
+}
+
+// ---- omega (oei.py:79-96) ------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n, int npad, int q,
+                                             const double* __restrict__ Xq,
+                                             const double* __restrict__ A,
+                                             const double* __restrict__ v,
+                                             double* __restrict__ omega) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    SdpWork w;
+    sdp_carve(w, sm, q);
+    double* mu = sm + sdp_work_doubles(q);
+    double* xq = mu + q + 2;
+    double* Ac = xq + q * kp.d;
+    double* vc = Ac + q * (CH + 1);
+    const int tid = threadIdx.x, b = blockIdx.x, k_ = q + 1, LD = w.LD;
+    for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
+    __syncthreads();
+    posterior_moments<T>(w, kp, noise, n, npad, A + (size_t)b * q * npad, v, xq, mu, Ac, vc);
+    double* om = omega + (size_t)b * k_ * k_;
+    for (int e = tid; e < k_ * k_; e += T) {
+        const int i = e / k_, j = e - i * k_;
+        double val;
+        if (i < q && j < q) val = w.S[i * LD + j] + mu[i] * mu[j];
+        else if (i < q) val = mu[i];
+        else if (j < q) val = mu[j];
+        else val = 1.0;
+        om[e] = val;
+    }
+}
+
+// ---- stage 2: moments -> SDP -> value, p, M11, Z = M11 A ------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, double fmin, int n,
+                                              int npad, int q, const double* __restrict__ Xq,
+                                              const double* __restrict__ A,
+                                              const double* __restrict__ v,
+                                              double* __restrict__ value, int* __restrict__ status,
+                                              double* __restrict__ p_out,
+                                              double* __restrict__ M11_out,
+                                              double* __restrict__ Z) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    SdpWork w;
+    sdp_carve(w, sm, q);
+    double* mu = sm + sdp_work_doubles(q);
+    double* xq = mu + q + 2;
+    double* Ac = xq + q * kp.d;
+    double* vc = Ac + q * (CH + 1);
+    const int tid = threadIdx.x, b = blockIdx.x, LD = w.LD;
+    for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
+    __syncthreads();
+    const double* Arows = A + (size_t)b * q * npad;
+    posterior_moments<T>(w, kp, noise, n, npad, Arows, v, xq, mu, Ac, vc);
+    if (tid < q) w.dl[tid] = mu[tid] - fmin;
+    __syncthreads();
+    double g = 0.0;
+    int it = 0;
+    const int st = sdp_solve<T>(w, &g, &it);
+    double* Zrows = Z + (size_t)b * q * npad;
+    if (st == 2) {
+        if (tid == 0) { value[b] = NAN; status[b] = 2; }
+        for (int e = tid; e < q; e += T) p_out[(size_t)b * q + e] = NAN;
+        for (int e = tid; e < q * q; e += T) M11_out[(size_t)b * q * q + e] = NAN;
+        for (int e = tid; e < q * npad; e += T) Zrows[e] = NAN;
+        return;
+    }
+    sdp_primal<T>(w, mu);       // N = B^-1 in w.H
+    if (tid == 0) { value[b] = -g; status[b] = st; }
+    for (int e = tid; e < q; e += T) p_out[(size_t)b * q + e] = w.p[e];
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, j = e - i * q;
+        M11_out[(size_t)b * q * q + e] = -w.H[i * LD + j];
+    }
+    // Z[a, k] = sum_b M11[a, b] A[b, k]
+    const int nchunks = npad / CH;
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        for (int e = tid; e < q * CH; e += T) {
+            const int a = e / CH, k = e - a * CH;
+            Ac[a * (CH + 1) + k] = Arows[(size_t)a * npad + c * CH + k];
+        }
+        __syncthreads();
+        for (int e = tid; e < q * CH; e += T) {
+            const int a = e / CH, k = e - a * CH;
+            double s = 0.0;
+            for (int bb = 0; bb < q; ++bb) s -= w.H[a * LD + bb] * Ac[bb * (CH + 1) + k];
+            Zrows[(size_t)a * npad + c * CH + k] = s;
+        }
+    }
+}
+
+// ---- gradient -------------------------------------------------------------------------------------
+// For each chunk of CH training points: ck[a][k] = (p_a alpha_k - 2 W[a,k]) * 2 var kappa'(t_ak),
+// then G[a][l] += sum_k ck[a][k] X[k][l] and G[a][d] += sum_k ck[a][k]; finally
+// grad[a][l] = (x_al G[a][d] - G[a][l]) / ls_l^2 + self terms.  Also raises the `project` flag.
+template <int T>
+__global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int q,
+                                            const double* __restrict__ Xtrain,
+                                            const double* __restrict__ alpha,
+                                            const double* __restrict__ Xq,
+                                            const double* __restrict__ Wm,
+                                            const double* __restrict__ p_in,
+                                            const double* __restrict__ M11_in,
+                                            double* __restrict__ grad, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int d = kp.d, dp = d + 1, dl = (d + 1) | 1;
+    double* xq = sm;                         // [q][d]
+    double* M11 = xq + q * d;                // [q][q]
+    double* pv = M11 + q * q;                // [q]
+    double* ck = pv + q;                     // [q][CH+1]
+    double* Xc = ck + q * (CH + 1);          // [CH][dl]   (column d holds 1)
+    double* Gs = Xc + CH * dl;               // [q][q]     2 var kappa'(t_ab)
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int e = tid; e < q * d; e += T) xq[e] = Xq[(size_t)b * q * d + e];
+    for (int e = tid; e < q * q; e += T) M11[e] = M11_in[(size_t)b * q * q + e];
+    for (int e = tid; e < q; e += T) pv[e] = p_in[(size_t)b * q + e];
+    __syncthreads();
+    const int nitems = q * dp;
+    double acc[ITEMS_MAX];
+#pragma unroll
+    for (int u = 0; u < ITEMS_MAX; ++u) acc[u] = 0.0;
+    int flag = 0;
+    const double* Wrows = Wm + (size_t)b * q * npad;
+    const int nchunks = (n + CH - 1) / CH;
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        for (int e = tid; e < CH * dp; e += T) {
+            const int k = e / dp, l = e - k * dp, kg = c * CH + k;
+            Xc[k * dl + l] = (l == d) ? 1.0 : ((kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0);
+        }
+        __syncthreads();
+        for (int e = tid; e < q * CH; e += T) {
+            const int a = e / CH, k = e - a * CH, kg = c * CH + k;
+            double t = 0.0;
+            bool close = true;
+            for (int l = 0; l < d; ++l) {
+                const double df = xq[a * d + l] - Xc[k * dl + l];
+                t += df * df * kp.inv_ls2[l];
+                close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
+            }
+            double k0, k1, k2;
+            kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+            double val = 0.0;
+            if (kg < n) {
+                val = (pv[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg]) * 2.0 * kp.variance * k1;
+                if (close) flag = 1;
+            }
+            ck[a * (CH + 1) + k] = val;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ITEMS_MAX; ++u) {
+            if (u * T >= nitems) break;                  // uniform; idle lanes redo item 0
+            const int e = (tid + u * T < nitems) ? tid + u * T : 0;
+            const int a = e / dp, l = e - a * dp;
+            const double* ca = ck + a * (CH + 1);
+            const double* xl = Xc + l;
+            double s = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < CH; ++k) s += ca[k] * xl[k * dl];
+            acc[u] += s;
+        }
+    }
+    // self-covariance derivative factors and mutual-duplicate test (oei.py:190)
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, bb = e - a * q;
+        double t = 0.0;
+        bool same = true;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - xq[bb * d + l];
+            t += df * df * kp.inv_ls2[l];
+            same = same && (rint(xq[a * d + l] / kp.ls[l] * 100.0) == rint(xq[bb * d + l] / kp.ls[l] * 100.0));
+        }
+        double k0, k1, k2;
+        kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        Gs[e] = (a == bb) ? 0.0 : 2.0 * kp.variance * k1;
+        if (a != bb && same) flag = 1;
+    }
+    __syncthreads();
+    double* Gacc = ck;      // reuse: [q][dp]
+#pragma unroll
+    for (int u = 0; u < ITEMS_MAX; ++u) {
+        const int e = tid + u * T;
+        if (e >= nitems) break;
+        Gacc[e] = acc[u];
+    }
+    __syncthreads();
+    for (int e = tid; e < q * d; e += T) {
+        const int a = e / d, l = e - a * d;
+        double gval = (xq[a * d + l] * Gacc[a * dp + d] - Gacc[a * dp + l]) * kp.inv_ls2[l];
+        double s = 0.0;
+        for (int bb = 0; bb < q; ++bb)
+            s += M11[a * q + bb] * Gs[a * q + bb] * (xq[a * d + l] - xq[bb * d + l]);
+        gval += 2.0 * s * kp.inv_ls2[l];
+        grad[(size_t)b * q * d + e] = gval;
+    }
+    if (flags) {
+        flag = __syncthreads_or(flag);
+        if (tid == 0) flags[b] = flag;
+    }
+}
+
+// ---- predict_f: mean_i = A_i . v, var_i = k(x_i,x_i) - |A_i|^2 (one wave per point) ---------------
+__global__ void k_predict(KernParams kp, int npad, const double* __restrict__ A,
+                          const double* __restrict__ v, double* __restrict__ mean,
+                          double* __restrict__ var) {
+    const size_t r = blockIdx.x;
+    double m = 0.0, s = 0.0;
+    for (int k = threadIdx.x; k < npad; k += 64) {
+        const double a = A[r * npad + k];
+        m += a * v[k];
+        s += a * a;
+    }
+    m = wave_sum(m); s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, 0.0, k0, k1, k2);
+        mean[r] = m;
+        var[r] = kp.variance * k0 - s;
+    }
+}
+
+// ---- arg-min with ties to the lowest index --------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_argmin(int B, const double* __restrict__ value,
+                                                 long long base, double* __restrict__ best_value,
+                                                 long long* __restrict__ best_index) {
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
+    double bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        const double x = value[i];
+        if (x < bv) { bv = x; bi = i; }      // strided scan keeps the lowest index per thread
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = sv[threadIdx.x + off];
+            const int oi = si[threadIdx.x + off];
+            if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *best_value = sv[0];
+        *best_index = (si[0] == 0x7fffffff) ? -1 : base + si[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+static int check_model_call(const oei_model* m, int B, int q, const void* X, const char* who) {
+    if (!m) { oei_set_error("%s: null model", who); return OEI_ERR_ARG; }
+    if (B < 0 || q < 1 || q > OEI_MAX_Q) { oei_set_error("%s: B=%d q=%d out of range (1 <= q <= %d)", who, B, q, OEI_MAX_Q); return OEI_ERR_ARG; }
+    if (B > 0 && !X) { oei_set_error("%s: null X", who); return OEI_ERR_ARG; }
+    return OEI_OK;
+}
+
+// gram + first GEMM for `rows` query points: leaves A = Ks L^-T in m->ws1 (Ks in m->ws0).
+static int cross_factor(oei_model* m, const double* Xq, size_t rows, size_t aux_bytes, hipStream_t st) {
+    const size_t rows_pad = round_up(rows, 64);
+    int rc = oei_ws_reserve(m, rows_pad, aux_bytes);
+    if (rc) return rc;
+    rc = oei_launch_gram(m, Xq, rows, rows_pad, m->ws0, st);
+    if (rc) return rc;
+    return oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows_pad, m->npad, 1, st);
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t lds) {
+    if (lds > 160 * 1024) { oei_set_error("LDS request %zu exceeds 160 KiB", lds); return OEI_ERR_ARG; }
+    if (lds > 48 * 1024)
+        OEI_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return OEI_OK;
+}
+
+extern "C" int oei_predict_f(oei_model* m, int npts, const double* X, double* mean, double* var,
+                             void* stream) {
+    if (!m || npts < 0 || (npts > 0 && (!X || !mean || !var))) { oei_set_error("predict_f: bad argument"); return OEI_ERR_ARG; }
+    if (npts == 0) return OEI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = cross_factor(m, X, (size_t)npts, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_predict, dim3(npts), dim3(64), 0, st, m->kp, m->npad, m->ws1, m->v, mean, var);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+extern "C" int oei_omega_batched(oei_model* m, int B, int q, const double* X, double* omega,
+                                 void* stream) {
+    int rc = check_model_call(m, B, q, X, "omega_batched");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    if (!omega) { oei_set_error("omega_batched: null output"); return OEI_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    rc = cross_factor(m, X, (size_t)B * q, 0, st);
+    if (rc) return rc;
+    const size_t lds = (sdp_work_doubles(q) + acq_extra_doubles(q, m->d)) * sizeof(double);
+    if (q <= 32) {
+        if ((rc = set_lds(k_omega<64>, lds))) return rc;
+        hipLaunchKernelGGL(k_omega<64>, dim3(B), dim3(64), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
+    } else {
+        if ((rc = set_lds(k_omega<256>, lds))) return rc;
+        hipLaunchKernelGGL(k_omega<256>, dim3(B), dim3(256), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
+    }
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* X, double* value,
+                                      double* grad, int* status, int* flags, void* stream) {
+    int rc = check_model_call(m, B, q, X, "value_grad_batched");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    if (!value || !grad || !status) { oei_set_error("value_grad_batched: null output"); return OEI_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    const int d = m->d;
+    const size_t rows = (size_t)B * q, rows_pad = round_up(rows, 64);
+    const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q) * sizeof(double);
+    rc = cross_factor(m, X, rows, aux_bytes, st);              // ws1 = A
+    if (rc) return rc;
+    double* p_buf = m->aux;
+    double* M11_buf = m->aux + (size_t)B * q;
+    const size_t lds2 = (sdp_work_doubles(q) + acq_extra_doubles(q, d)) * sizeof(double);
+    const size_t ldsg = ((size_t)q * d + 2 * (size_t)q * q + q + (size_t)q * (CH + 1) + (size_t)CH * ((d + 1) | 1)) * sizeof(double);
+    if (q * (d + 1) > ITEMS_MAX * (q <= 32 ? 64 : 256) || q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
+        oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
+        return OEI_ERR_ARG;
+    }
+    if (q <= 32) {
+        if ((rc = set_lds(k_stage2<64>, lds2))) return rc;
+        hipLaunchKernelGGL(k_stage2<64>, dim3(B), dim3(64), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, m->ws1, m->v, value, status, p_buf, M11_buf, m->ws0);
+    } else {
+        if ((rc = set_lds(k_stage2<256>, lds2))) return rc;
+        hipLaunchKernelGGL(k_stage2<256>, dim3(B), dim3(256), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, m->ws1, m->v, value, status, p_buf, M11_buf, m->ws0);
+    }
+    OEI_HIP_CHECK(hipGetLastError());
+    if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
+        OEI_HIP_CHECK(hipMemsetAsync(m->ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
+    rc = oei_launch_gemm_nt(m->ws0, m->LinvT, m->ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
+    if (rc) return rc;
+    if (q <= 32) {
+        if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
+        hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+    } else {
+        if ((rc = set_lds(k_grad<256>, ldsg))) return rc;
+        hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+    }
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+extern "C" int oei_argmin(int B, const double* value, long long index_base, double* best_value,
+                          long long* best_index, void* stream) {
+    if (B < 0 || !best_value || !best_index || (B > 0 && !value)) { oei_set_error("argmin: bad argument"); return OEI_ERR_ARG; }
+    hipLaunchKernelGGL(k_argmin, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, value, index_base, best_value, best_index);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}

@@ -1,0 +1,107 @@
+// Shared declarations for the gfx950 OEI library: error plumbing, the model handle, kernel
+// parameter block and small device helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "../../include/oei_hip.h"
+
+#define OEI_ABI_VERSION 1
+#define OEI_NPAD 64            // training size is padded to a multiple of this (GEMM tile)
+
+void oei_set_error(const char* fmt, ...);
+
+#define OEI_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            oei_set_error("%s failed at %s:%d: %s", #expr, __FILE__, __LINE__,           \
+                          hipGetErrorString(_e));                                        \
+            return OEI_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+// Kernel hyper-parameters, passed by value to kernels.
+struct KernParams {
+    int kind;                       // OEI_KERNEL_*
+    int floor_mode;                 // OEI_FLOOR_*
+    int d;
+    double variance;
+    double inv_ls2[OEI_MAX_DIM];    // 1 / lengthscale^2 per dimension
+    double inv_ls[OEI_MAX_DIM];     // 1 / lengthscale
+    double ls[OEI_MAX_DIM];         // lengthscale
+};
+
+struct oei_model {
+    int device;
+    int n, d, npad;
+    double noise;
+    double fmin;
+    KernParams kp;
+    double* X;        // [npad, d]   training inputs (padding rows are zero)
+    double* L;        // [npad, npad] lower Cholesky factor of K + noise I (identity in the padding)
+    double* Linv;     // [npad, npad] L^-1 (lower)
+    double* LinvT;    // [npad, npad] L^-T (upper), row-major
+    double* v;        // [npad] L^-1 y
+    double* alpha;    // [npad] K^-1 y
+    double* y;        // [npad]
+    // scratch, grown on demand (row counts are in candidate points)
+    size_t ws_rows;   // rows currently allocated in each of ws0/ws1
+    double* ws0;      // [rows, npad]
+    double* ws1;      // [rows, npad]
+    size_t aux_bytes;
+    double* aux;      // per-candidate state (p, M11, ...)
+};
+
+// ---- device helpers ---------------------------------------------------------------------------
+
+// kappa(t) and (optionally) its first and second derivatives with respect to t = r2.
+// k(x,x') = variance * kappa(r2).
+template <int ORDER>
+__device__ __forceinline__ void kappa_eval(int kind, int floor_mode, double t,
+                                           double& k0, double& k1, double& k2) {
+    if (kind == OEI_KERNEL_RBF) {
+        double e = exp(-0.5 * t);
+        k0 = e;
+        if (ORDER >= 1) k1 = -0.5 * e;
+        if (ORDER >= 2) k2 = 0.25 * e;
+    } else {
+        double r;
+        bool live;
+        if (floor_mode == OEI_FLOOR_STOCK) { r = sqrt(t + 1e-12); live = true; }
+        else if (floor_mode == OEI_FLOOR_SAFE) { r = sqrt(fmax(t, 1e-40)); live = t > 1e-40; }
+        else { r = sqrt(t); live = t > 0.0; }
+        const double s3 = 1.7320508075688772;
+        double e = exp(-s3 * r);
+        k0 = (1.0 + s3 * r) * e;
+        if (ORDER >= 1) k1 = live ? -1.5 * e : 0.0;
+        if (ORDER >= 2) k2 = live ? 0.75 * s3 * e / r : 0.0;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- internal launch helpers (defined across the .hip files) -----------------------------------
+int oei_ws_reserve(oei_model* m, size_t rows, size_t aux_bytes);
+
+// Ks[r, k] = k(x_r, X_k) for r < rows (x_r = row r of Xq [rows, d]); zero for r >= rows or k >= n.
+// MODE 0: kernel value; MODE 1..d: derivative of k(x_r, X_k) with respect to x_r[MODE-1].
+int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
+                    double* Ks, hipStream_t st);
+// Kd[(r*d + l), k] = d k(x_r, X_k) / d x_r[l]
+int oei_launch_gram_deriv(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
+                          double* Kd, hipStream_t st);
+// C[r, j] = sum_k A[r, k] * Bm[j, k], all [*, npad] row-major; `lower` != 0 means Bm is lower
+// triangular (k <= j), else upper triangular (k >= j).
+int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,
+                       int lower, hipStream_t st);

@@ -1,0 +1,369 @@
+// GP model handle: one-time set-up of everything that is shared by all candidate batches.
+//
+//   K = k(X,X) + noise I  ->  blocked right-looking Cholesky (64x64 blocks)  ->  L
+//   L^-1 by blocked triangular inversion, L^-T, v = L^-1 y, alpha = L^-T v,
+//   fmin = min_i (k(X_i, X) alpha)            (posterior mean at the training inputs, oei.py:27)
+//
+// gpflow recomputes the Cholesky factor inside every Session.run of the reference (three times per
+// acquisition call); here it is computed once per model and kept in HBM (8 MB at n = 1000).
+#include "oei_common.h"
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+
+static thread_local char g_err[512] = "no error";
+
+void oei_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* oei_last_error(void) { return g_err; }
+extern "C" int oei_abi_version(void) { return OEI_ABI_VERSION; }
+
+#define TB 64          // block size of the blocked factorisation
+#define TLD 65         // LDS leading dimension (odd: conflict-free column walks)
+
+// ---- K = k(X,X) + noise I, identity in the padding ---------------------------------------------
+__global__ void k_gram_train(KernParams kp, const double* __restrict__ X, int n, int npad,
+                             double noise, double* __restrict__ K) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= npad) return;
+    double val;
+    if (i < n && j < n) {
+        double t = 0.0;
+        for (int l = 0; l < kp.d; ++l) {
+            double df = X[(size_t)i * kp.d + l] - X[(size_t)j * kp.d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        val = kp.variance * k0 + (i == j ? noise : 0.0);
+    } else {
+        val = (i == j) ? 1.0 : 0.0;
+    }
+    K[(size_t)i * npad + j] = val;
+}
+
+// ---- 64x64 tile product helper: acc(4x4 per thread) += A(64x64) * op(B)(64x64) -----------------
+// thread (ty, tx) = (tid / 16, tid % 16) owns rows 4*ty.., cols 4*tx..
+template <bool TRANSB>
+__device__ __forceinline__ void tile_mm(double acc[4][4], const double* __restrict__ A, int lda,
+                                        const double* __restrict__ Bt, int ldb, double* As,
+                                        double* Bs) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) {
+        int r = e / TB, c = e % TB;
+        As[r * TLD + c] = A[(size_t)r * lda + c];
+        // Bs[k][j] = op(B)[k][j]
+        Bs[r * TLD + c] = TRANSB ? Bt[(size_t)c * ldb + r] : Bt[(size_t)r * ldb + c];
+    }
+    __syncthreads();
+    const int ty = tid / 16, tx = tid % 16;
+    for (int k = 0; k < TB; ++k) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = As[(4 * ty + u) * TLD + k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = Bs[k * TLD + 4 * tx + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc[u][w] += a[u] * b[w];
+    }
+}
+
+// ---- diagonal block: Cholesky of A_kk in LDS, plus its inverse ---------------------------------
+__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ Lm, int npad, int kb,
+                                               double* __restrict__ Dinv, int* __restrict__ flag) {
+    __shared__ double T[TB * TLD];
+    __shared__ double Ti[TB * TLD];
+    const int tid = threadIdx.x;
+    double* Ablk = Lm + ((size_t)kb * TB) * npad + (size_t)kb * TB;
+    for (int e = tid; e < TB * TB; e += 256) T[(e / TB) * TLD + e % TB] = Ablk[(size_t)(e / TB) * npad + e % TB];
+    __syncthreads();
+    for (int k = 0; k < TB; ++k) {
+        double dkk = T[k * TLD + k];
+        if (!(dkk > 0.0)) { if (tid == 0) *flag = 1; dkk = 1.0; }
+        double piv = sqrt(dkk);
+        __syncthreads();
+        if (tid == 0) T[k * TLD + k] = piv;
+        for (int i = k + 1 + tid; i < TB; i += 256) T[i * TLD + k] /= piv;
+        __syncthreads();
+        for (int e = tid; e < (TB - k - 1) * (TB - k - 1); e += 256) {
+            int i = k + 1 + e / (TB - k - 1), j = k + 1 + e % (TB - k - 1);
+            if (j <= i) T[i * TLD + j] -= T[i * TLD + k] * T[j * TLD + k];
+        }
+        __syncthreads();
+    }
+    // inverse of the lower-triangular block: thread j builds column j by forward substitution
+    if (tid < TB) {
+        const int j = tid;
+        for (int i = 0; i < TB; ++i) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int k = j; k < i; ++k) s -= T[i * TLD + k] * Ti[k * TLD + j];
+            Ti[i * TLD + j] = (i < j) ? 0.0 : s / T[i * TLD + i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) {
+        int r = e / TB, c = e % TB;
+        Ablk[(size_t)r * npad + c] = (c <= r) ? T[r * TLD + c] : 0.0;
+        Dinv[(size_t)kb * TB * TB + e] = Ti[r * TLD + c];
+    }
+}
+
+// ---- panel: L_ik = A_ik * inv(L_kk)^T for i > k -------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ Lm, int npad, int kb,
+                                                    const double* __restrict__ Dinv) {
+    __shared__ double As[TB * TLD];
+    __shared__ double Bs[TB * TLD];
+    const int ib = kb + 1 + blockIdx.x;
+    double* Ablk = Lm + ((size_t)ib * TB) * npad + (size_t)kb * TB;
+    double acc[4][4] = {};
+    tile_mm<true>(acc, Ablk, npad, Dinv + (size_t)kb * TB * TB, TB, As, Bs);
+    __syncthreads();
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    for (int u = 0; u < 4; ++u)
+        for (int w = 0; w < 4; ++w) Ablk[(size_t)(4 * ty + u) * npad + 4 * tx + w] = acc[u][w];
+}
+
+// ---- trailing update: A_ij -= L_ik L_jk^T for i >= j > k ---------------------------------------
+__global__ __launch_bounds__(256) void k_syrk_trail(double* __restrict__ Lm, int npad, int kb) {
+    __shared__ double As[TB * TLD];
+    __shared__ double Bs[TB * TLD];
+    const int ib = kb + 1 + blockIdx.y;
+    const int jb = kb + 1 + blockIdx.x;
+    if (jb > ib) return;
+    const double* Lik = Lm + ((size_t)ib * TB) * npad + (size_t)kb * TB;
+    const double* Ljk = Lm + ((size_t)jb * TB) * npad + (size_t)kb * TB;
+    double acc[4][4] = {};
+    tile_mm<true>(acc, Lik, npad, Ljk, npad, As, Bs);
+    double* Aij = Lm + ((size_t)ib * TB) * npad + (size_t)jb * TB;
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    for (int u = 0; u < 4; ++u)
+        for (int w = 0; w < 4; ++w) Aij[(size_t)(4 * ty + u) * npad + 4 * tx + w] -= acc[u][w];
+}
+
+// ---- zero the strict upper triangle of block row 0.. (blocks above the diagonal) ---------------
+__global__ void k_zero_upper(double* __restrict__ Lm, int npad) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < npad && j > i) Lm[(size_t)i * npad + j] = 0.0;
+}
+
+// ---- L^-1: block column jb is built top-down by one workgroup ----------------------------------
+// Linv_jj = inv(L_jj);  Linv_ij = -inv(L_ii) * sum_{k=j}^{i-1} L_ik Linv_kj   (i > j)
+__global__ __launch_bounds__(256) void k_trinv(const double* __restrict__ Lm, int npad,
+                                               const double* __restrict__ Dinv,
+                                               double* __restrict__ Linv, double* __restrict__ tmp) {
+    __shared__ double As[TB * TLD];
+    __shared__ double Bs[TB * TLD];
+    const int nb = npad / TB;
+    const int jb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int ty = tid / 16, tx = tid % 16;
+    // zero blocks above the diagonal, copy the diagonal inverse
+    for (int ib = 0; ib < jb; ++ib)
+        for (int e = tid; e < TB * TB; e += 256)
+            Linv[((size_t)ib * TB + e / TB) * npad + (size_t)jb * TB + e % TB] = 0.0;
+    for (int e = tid; e < TB * TB; e += 256)
+        Linv[((size_t)jb * TB + e / TB) * npad + (size_t)jb * TB + e % TB] = Dinv[(size_t)jb * TB * TB + e];
+    __threadfence_block();
+    __syncthreads();
+    double* T = tmp + (size_t)jb * TB * TB;     // per-workgroup scratch tile
+    for (int ib = jb + 1; ib < nb; ++ib) {
+        double acc[4][4] = {};
+        for (int kb = jb; kb < ib; ++kb)
+            tile_mm<false>(acc, Lm + ((size_t)ib * TB) * npad + (size_t)kb * TB, npad,
+                           Linv + ((size_t)kb * TB) * npad + (size_t)jb * TB, npad, As, Bs);
+        __syncthreads();
+        for (int u = 0; u < 4; ++u)
+            for (int w = 0; w < 4; ++w) T[(4 * ty + u) * TB + 4 * tx + w] = acc[u][w];
+        __threadfence_block();
+        __syncthreads();
+        double acc2[4][4] = {};
+        tile_mm<false>(acc2, Dinv + (size_t)ib * TB * TB, TB, T, TB, As, Bs);
+        for (int u = 0; u < 4; ++u)
+            for (int w = 0; w < 4; ++w)
+                Linv[((size_t)ib * TB + 4 * ty + u) * npad + (size_t)jb * TB + 4 * tx + w] = -acc2[u][w];
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ void k_transpose(const double* __restrict__ A, double* __restrict__ At, int npad) {
+    __shared__ double t[32][33];
+    int x = blockIdx.x * 32 + threadIdx.x, y = blockIdx.y * 32 + threadIdx.y;
+    t[threadIdx.y][threadIdx.x] = A[(size_t)y * npad + x];
+    __syncthreads();
+    x = blockIdx.y * 32 + threadIdx.x; y = blockIdx.x * 32 + threadIdx.y;
+    At[(size_t)y * npad + x] = t[threadIdx.x][threadIdx.y];
+}
+
+// out[i] = sum_j Mat[i][j] * vec[j]   (one wave per row)
+__global__ void k_matvec(const double* __restrict__ Mat, const double* __restrict__ vec,
+                         double* __restrict__ out, int npad) {
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < npad; j += 64) s += Mat[(size_t)i * npad + j] * vec[j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[i] = s;
+}
+
+// mean_i = sum_j k(X_i, X_j) alpha_j for i < n  -> global minimum (single block)
+__global__ __launch_bounds__(256) void k_fmin(KernParams kp, const double* __restrict__ X, int n,
+                                              const double* __restrict__ alpha,
+                                              double* __restrict__ fmin_out) {
+    __shared__ double red[4];
+    double best = INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) {
+            double t = 0.0;
+            for (int l = 0; l < kp.d; ++l) {
+                double df = X[(size_t)i * kp.d + l] - X[(size_t)j * kp.d + l];
+                t += df * df * kp.inv_ls2[l];
+            }
+            double k0, k1, k2;
+            kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+            s += kp.variance * k0 * alpha[j];
+        }
+        best = fmin(best, s);
+    }
+    best = wave_min(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) *fmin_out = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+static void model_free(oei_model* m) {
+    if (!m) return;
+    hipFree(m->X); hipFree(m->L); hipFree(m->Linv); hipFree(m->LinvT);
+    hipFree(m->v); hipFree(m->alpha); hipFree(m->y);
+    hipFree(m->ws0); hipFree(m->ws1); hipFree(m->aux);
+    delete m;
+}
+
+extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_train,
+                                const double* y, int kernel_kind, int floor_mode, double variance,
+                                const double* lengthscales, int n_lengthscales, double noise) {
+    if (!out || !X_train || !y || !lengthscales) { oei_set_error("model_create: null pointer"); return OEI_ERR_ARG; }
+    if (n < 1 || d < 1 || d > OEI_MAX_DIM) { oei_set_error("model_create: n=%d d=%d out of range (d <= %d)", n, d, OEI_MAX_DIM); return OEI_ERR_ARG; }
+    if (kernel_kind != OEI_KERNEL_RBF && kernel_kind != OEI_KERNEL_MATERN32) { oei_set_error("model_create: unknown kernel %d", kernel_kind); return OEI_ERR_ARG; }
+    if (floor_mode < 0 || floor_mode > 2) { oei_set_error("model_create: unknown floor mode %d", floor_mode); return OEI_ERR_ARG; }
+    if (n_lengthscales != 1 && n_lengthscales != d) { oei_set_error("model_create: need 1 or d lengthscales"); return OEI_ERR_ARG; }
+    if (!(variance > 0.0) || !(noise >= 0.0)) { oei_set_error("model_create: variance/noise out of range"); return OEI_ERR_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { oei_set_error("no HIP device"); return OEI_ERR_NO_DEVICE; }
+
+    oei_model* m = new oei_model();
+    memset(m, 0, sizeof(*m));
+    OEI_HIP_CHECK(hipGetDevice(&m->device));
+    m->n = n; m->d = d; m->noise = noise;
+    m->npad = ((n + OEI_NPAD - 1) / OEI_NPAD) * OEI_NPAD;
+    m->kp.kind = kernel_kind; m->kp.floor_mode = floor_mode; m->kp.d = d; m->kp.variance = variance;
+    for (int l = 0; l < d; ++l) {
+        double ls = lengthscales[n_lengthscales == 1 ? 0 : l];
+        if (!(ls > 0.0)) { delete m; oei_set_error("model_create: lengthscale <= 0"); return OEI_ERR_ARG; }
+        m->kp.inv_ls[l] = 1.0 / ls;
+        m->kp.ls[l] = ls;
+        m->kp.inv_ls2[l] = 1.0 / (ls * ls);
+    }
+    const int npad = m->npad;
+    const size_t nn = (size_t)npad * npad * sizeof(double);
+    double *Dinv = nullptr, *tmp = nullptr, *dfmin = nullptr; int* dflag = nullptr;
+    int rc = OEI_OK;
+    auto body = [&]() -> int {
+        OEI_HIP_CHECK(hipMalloc(&m->X, (size_t)npad * d * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->L, nn));
+        OEI_HIP_CHECK(hipMalloc(&m->Linv, nn));
+        OEI_HIP_CHECK(hipMalloc(&m->LinvT, nn));
+        OEI_HIP_CHECK(hipMalloc(&m->v, npad * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->alpha, npad * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->y, npad * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&Dinv, (size_t)npad * TB * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&tmp, (size_t)npad * TB * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&dfmin, sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&dflag, sizeof(int)));
+        OEI_HIP_CHECK(hipMemset(m->X, 0, (size_t)npad * d * sizeof(double)));
+        OEI_HIP_CHECK(hipMemset(m->y, 0, npad * sizeof(double)));
+        OEI_HIP_CHECK(hipMemset(dflag, 0, sizeof(int)));
+        OEI_HIP_CHECK(hipMemcpy(m->X, X_train, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice));
+        OEI_HIP_CHECK(hipMemcpy(m->y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+        hipStream_t st = 0;
+        hipLaunchKernelGGL(k_gram_train, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->kp, m->X, n, npad, noise, m->L);
+        const int nb = npad / TB;
+        for (int kb = 0; kb < nb; ++kb) {
+            hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), 0, st, m->L, npad, kb, Dinv, dflag);
+            const int rem = nb - kb - 1;
+            if (rem > 0) {
+                hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), 0, st, m->L, npad, kb, Dinv);
+                hipLaunchKernelGGL(k_syrk_trail, dim3(rem, rem), dim3(256), 0, st, m->L, npad, kb);
+            }
+        }
+        hipLaunchKernelGGL(k_zero_upper, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->L, npad);
+        hipLaunchKernelGGL(k_trinv, dim3(nb), dim3(256), 0, st, m->L, npad, Dinv, m->Linv, tmp);
+        hipLaunchKernelGGL(k_transpose, dim3(npad / 32, npad / 32), dim3(32, 32), 0, st, m->Linv, m->LinvT, npad);
+        hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->Linv, m->y, m->v, npad);
+        hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->LinvT, m->v, m->alpha, npad);
+        hipLaunchKernelGGL(k_fmin, dim3(1), dim3(256), 0, st, m->kp, m->X, n, m->alpha, dfmin);
+        OEI_HIP_CHECK(hipGetLastError());
+        OEI_HIP_CHECK(hipDeviceSynchronize());
+        int flag = 0;
+        OEI_HIP_CHECK(hipMemcpy(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost));
+        OEI_HIP_CHECK(hipMemcpy(&m->fmin, dfmin, sizeof(double), hipMemcpyDeviceToHost));
+        if (flag) { oei_set_error("model_create: K + noise*I is not positive definite"); return OEI_ERR_NOT_PD; }
+        return OEI_OK;
+    };
+    rc = body();
+    hipFree(Dinv); hipFree(tmp); hipFree(dfmin); hipFree(dflag);
+    if (rc != OEI_OK) { model_free(m); return rc; }
+    *out = m;
+    return OEI_OK;
+}
+
+extern "C" int oei_model_destroy(oei_model* m) {
+    if (!m) return OEI_OK;
+    hipSetDevice(m->device);
+    model_free(m);
+    return OEI_OK;
+}
+
+extern "C" int oei_model_info(const oei_model* m, double* fmin, int* n, int* d) {
+    if (!m) { oei_set_error("model_info: null model"); return OEI_ERR_ARG; }
+    if (fmin) *fmin = m->fmin;
+    if (n) *n = m->n;
+    if (d) *d = m->d;
+    return OEI_OK;
+}
+
+extern "C" int oei_model_get_factor(const oei_model* m, double* L_host) {
+    if (!m || !L_host) { oei_set_error("model_get_factor: null pointer"); return OEI_ERR_ARG; }
+    OEI_HIP_CHECK(hipMemcpy2D(L_host, (size_t)m->n * sizeof(double), m->L, (size_t)m->npad * sizeof(double),
+                              (size_t)m->n * sizeof(double), m->n, hipMemcpyDeviceToHost));
+    return OEI_OK;
+}
+
+int oei_ws_reserve(oei_model* m, size_t rows, size_t aux_bytes) {
+    if (rows > m->ws_rows) {
+        if (m->ws0) OEI_HIP_CHECK(hipFree(m->ws0));
+        if (m->ws1) OEI_HIP_CHECK(hipFree(m->ws1));
+        m->ws0 = m->ws1 = nullptr; m->ws_rows = 0;
+        OEI_HIP_CHECK(hipMalloc(&m->ws0, rows * (size_t)m->npad * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->ws1, rows * (size_t)m->npad * sizeof(double)));
+        m->ws_rows = rows;
+    }
+    if (aux_bytes > m->aux_bytes) {
+        if (m->aux) OEI_HIP_CHECK(hipFree(m->aux));
+        m->aux = nullptr; m->aux_bytes = 0;
+        OEI_HIP_CHECK(hipMalloc(&m->aux, aux_bytes));
+        m->aux_bytes = aux_bytes;
+    }
+    return OEI_OK;
+}

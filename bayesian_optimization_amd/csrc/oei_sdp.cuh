@@ -1,0 +1,416 @@
+// Device-side solver for the OEI semidefinite program, one workgroup per candidate.
+//
+//   value = max_M <Omega, M>  s.t.  C_i - M >= 0,  i = 0..q        (reference: sdp.py:11-67)
+//
+// The reference hands this cone program (k_ PSD blocks of side k_ = q+1) to a first-order solver.
+// Here the k_ Schur complements are eliminated analytically.  With
+// Omega = w0 [[S + mu mu^T, mu], [mu^T, 1]], delta = mu - fmin, the problem is equivalent to the
+// smooth concave maximisation over the open simplex {p > 0, sum p < 1}
+//
+//   g(p) = tr (S^1/2 D(p) S^1/2)^1/2 - p^T delta,     D(p) = diag(p) - p p^T,     value = -w0 max g,
+//
+// where p_i is the weight of the i-th rank-one dual block Y_i (p_0 = 1 - sum p that of Y_0).
+// g is maximised by a damped Newton iteration.  Every evaluation needs one symmetric
+// eigendecomposition of the q x q matrix X = W S W^T (D = W^T W), done with a cyclic two-sided
+// Jacobi iteration whose rotations are applied as independent 2x2 blocks, all in LDS:
+//
+//   W = (I - gamma s s^T) diag(s),  s = sqrt(p),  gamma = 1/(1 + sqrt(p0))
+//   X = V diag(lam) V^T,  sq = sqrt(lam),  R = W^-1 V,  U = W^T V
+//   B = 2 R diag(sq) R^T,   N = B^-1 = 1/2 U diag(1/sq) U^T
+//   grad g = diag(B)/4 - B p/2 - delta
+//   hess g = -1/2 sum_ab K_ab E_i,ab E_j,ab - B/2,   K_ab = 1/(sq_a sq_b (sq_a + sq_b)),
+//            E_i = w_i w_i^T - m m^T,  u_i = sq * R[i,:],  m = sum p_i u_i,  w_i = u_i - m
+//   M = -[[N, -N c], [-(N c)^T, c^T N c]],  c = mu + B p / 2
+//   y_0 = sqrt(w0 p0) [c; 1],  y_i = sqrt(w0 p_i) [c - B e_i / 2; 1],  Y_i = y_i y_i^T
+//
+// All matrices are q x q with an odd leading dimension LD so that row and column walks are free
+// of LDS bank conflicts.  Every thread of the workgroup executes every call (barriers inside).
+#pragma once
+#include "oei_common.h"
+
+#define SDP_MAX_NEWTON 60
+#define SDP_MAX_SWEEPS 30
+#define SDP_JACOBI_TOL 1e-15
+#define SDP_STEP_TOL 1e-7
+
+struct SdpWork {
+    int q, LD;
+    double *S, *X, *V, *R, *H, *Kt;                                // q x LD matrices
+    double *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci;  // vectors (length q)
+    double *rc, *rs, *rt;                                          // rotation parameters
+    int *ri, *rj;
+    double *scal;                                                  // [8] scalars
+};
+
+__host__ __device__ inline int sdp_ld(int q) { return q | 1; }
+__host__ __device__ inline int sdp_vlen(int q) { return (q + 3) & ~1; }   // even, >= q + 2
+
+__host__ __device__ inline size_t sdp_work_doubles(int q) {
+    const int LD = sdp_ld(q), VL = sdp_vlen(q);
+    return (size_t)6 * q * LD + (size_t)11 * VL + 3 * VL + VL /* ri,rj as ints */ + 8;
+}
+
+__device__ inline void sdp_carve(SdpWork& w, double* base, int q) {
+    const int LD = sdp_ld(q), VL = sdp_vlen(q);
+    w.q = q; w.LD = LD;
+    double* ptr = base;
+    w.S = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;  w.V = ptr; ptr += q * LD;
+    w.R = ptr; ptr += q * LD;  w.H = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD;
+    w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
+    w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
+    w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;
+    w.rc = ptr; ptr += VL; w.rs = ptr; ptr += VL;  w.rt = ptr; ptr += VL;
+    w.ri = reinterpret_cast<int*>(ptr); w.rj = w.ri + VL; ptr += VL;
+    w.scal = ptr;
+}
+
+// ---- cyclic Jacobi on w.X (symmetric, full storage); eigenvectors accumulate in w.V ------------
+// Round-robin ordering: in round r, slot 0 pairs (qe-1, r) and slot k pairs ((r+k), (r-k)) mod
+// (qe-1); qe = q rounded up to even, pairs touching the padding index are idle.  For one round the
+// np x np grid of 2x2 blocks X[{i_k,j_k},{i_l,j_l}] <- J_k^T (.) J_l is updated independently.
+template <int T>
+__device__ int sdp_jacobi(const SdpWork& w) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const int qe = q + (q & 1), np = qe >> 1, nm1 = qe - 1;
+    double* X = w.X;
+    double* V = w.V;
+    int sweep = 0;
+    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
+        int rotated = 0;
+        for (int r = 0; r < nm1; ++r) {
+            int flag = 0;
+            if (tid < np) {
+                int a, b;
+                if (tid == 0) { a = nm1; b = r; }
+                else { a = r + tid; if (a >= nm1) a -= nm1; b = r - tid; if (b < 0) b += nm1; }
+                const int i = a < b ? a : b, j = a < b ? b : a;
+                double c = 1.0, s = 0.0, t = 0.0;
+                if (j < q) {
+                    const double xii = X[i * LD + i], xjj = X[j * LD + j], xij = X[i * LD + j];
+                    const double thr = SDP_JACOBI_TOL * SDP_JACOBI_TOL * fabs(xii * xjj);
+                    if (xij * xij > thr && xij != 0.0) {
+                        const double zeta = (xjj - xii) / (2.0 * xij);
+                        t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        if (zeta < 0.0) t = -t;
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        s = t * c;
+                        flag = 1;
+                    }
+                }
+                w.ri[tid] = i; w.rj[tid] = (j < q) ? j : -1;
+                w.rc[tid] = c; w.rs[tid] = s; w.rt[tid] = t;
+            }
+            const int any = __syncthreads_or(flag);
+            if (!any) continue;
+            rotated = 1;
+            const int nblk = np * np;
+            for (int e = tid; e < nblk + q * np; e += T) {
+                if (e < nblk) {
+                    const int k = e / np, l = e - k * np;
+                    const int ik = w.ri[k], jk = w.rj[k], il = w.ri[l], jl = w.rj[l];
+                    // a slot whose partner is the padding index (j < 0) is a lone row/column:
+                    // it is not rotated itself but still sees the other slots' rotations
+                    if (k == l) {
+                        if (jk < 0) continue;
+                        const double t = w.rt[k];
+                        const double xij = X[ik * LD + jk];
+                        X[ik * LD + ik] -= t * xij;
+                        X[jk * LD + jk] += t * xij;
+                        if (w.rs[k] != 0.0) { X[ik * LD + jk] = 0.0; X[jk * LD + ik] = 0.0; }
+                    } else {
+                        const bool hk = jk >= 0, hl = jl >= 0;
+                        const double ck = w.rc[k], sk = w.rs[k], cl = w.rc[l], sl = w.rs[l];
+                        const double a = X[ik * LD + il];
+                        const double b = hl ? X[ik * LD + jl] : 0.0;
+                        const double c = hk ? X[jk * LD + il] : 0.0;
+                        const double d = (hk && hl) ? X[jk * LD + jl] : 0.0;
+                        const double a1 = ck * a - sk * c, b1 = ck * b - sk * d;
+                        const double c1 = sk * a + ck * c, d1 = sk * b + ck * d;
+                        X[ik * LD + il] = cl * a1 - sl * b1;
+                        if (hl) X[ik * LD + jl] = sl * a1 + cl * b1;
+                        if (hk) X[jk * LD + il] = cl * c1 - sl * d1;
+                        if (hk && hl) X[jk * LD + jl] = sl * c1 + cl * d1;
+                    }
+                } else {
+                    const int f = e - nblk;
+                    const int row = f / np, l = f - row * np;
+                    const int il = w.ri[l], jl = w.rj[l];
+                    if (jl < 0) continue;
+                    const double cl = w.rc[l], sl = w.rs[l];
+                    const double vi = V[row * LD + il], vj = V[row * LD + jl];
+                    V[row * LD + il] = cl * vi - sl * vj;
+                    V[row * LD + jl] = sl * vi + cl * vj;
+                }
+            }
+            __syncthreads();
+        }
+        if (!rotated) break;
+    }
+    return sweep;
+}
+
+// ---- evaluate g, grad g and the eigen-state at the point pt (length q, in LDS) ------------------
+// Returns g, or -inf when pt leaves the simplex or X loses positive definiteness numerically.
+template <int T>
+__device__ double sdp_eval(const SdpWork& w, const double* pt, int& sweeps) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    double sum = 0.0, pmin = INFINITY;
+    for (int i = 0; i < q; ++i) { sum += pt[i]; pmin = fmin(pmin, pt[i]); }
+    const double p0 = 1.0 - sum;
+    if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
+    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), gamp = gam / sp0;
+    __syncthreads();           // previous readers of s/tv/X/V are done
+    if (tid < q) {
+        w.s[tid] = sqrt(pt[tid]);
+        double acc = 0.0;
+        for (int j = 0; j < q; ++j) acc += w.S[tid * LD + j] * pt[j];
+        w.tv[tid] = acc;
+    }
+    __syncthreads();
+    double tau = 0.0;
+    for (int i = 0; i < q; ++i) tau += pt[i] * w.tv[i];
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, j = e - i * q;
+        w.X[i * LD + j] = w.s[i] * w.s[j] * (w.S[i * LD + j] - gam * (w.tv[i] + w.tv[j]) + gam * gam * tau);
+        w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    sweeps += sdp_jacobi<T>(w);
+    __syncthreads();
+    int bad = 0;
+    if (tid < q) {
+        const double lam = w.X[tid * LD + tid];
+        if (!(lam > 0.0)) bad = 1;
+        w.sq[tid] = sqrt(fmax(lam, 1e-300));
+        double acc = 0.0;
+        for (int k = 0; k < q; ++k) acc += w.s[k] * w.V[k * LD + tid];
+        w.sv[tid] = acc;
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) return -INFINITY;
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        w.R[i * LD + a] = w.V[i * LD + a] / w.s[i] + gamp * w.sv[a];
+    }
+    __syncthreads();
+    if (tid < q) {
+        double acc = 0.0;
+        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * pt[i];
+        w.rp[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < q) {
+        double db = 0.0, bp = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
+            db += r * rs;
+            bp += rs * w.rp[a];
+        }
+        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
+    }
+    __syncthreads();
+    double g = 0.0;
+    for (int a = 0; a < q; ++a) g += w.sq[a] - pt[a] * w.dl[a];
+    return g;
+}
+
+// ---- Newton direction at the state left by sdp_eval(w.p): w.step = (-hess g)^-1 grad g ----------
+// Returns 0 on success, 1 if -hess g is not numerically positive definite.
+template <int T>
+__device__ int sdp_newton_dir(const SdpWork& w) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    double* Wv = w.X;      // eigen-decomposition finished: X and V are free for reuse
+    double* Bh = w.V;      // B/2 = R sq R^T
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        const double m = w.sq[a] * w.rp[a];
+        Wv[i * LD + a] = w.R[i * LD + a] * w.sq[a] - m;
+        w.Kt[i * LD + a] = 1.0 / (w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
+    }
+    __syncthreads();
+    // ci[i] = sum_ab K_ab w_ia w_ib m_a m_b ;  c0 = sum_ab K_ab m_a^2 m_b^2 (via tv)
+    if (tid < q) {
+        const int i = tid;
+        double acc = 0.0, acc0 = 0.0;
+        const double mi = w.sq[i] * w.rp[i];
+        for (int a = 0; a < q; ++a) {
+            const double ma = w.sq[a] * w.rp[a];
+            const double wa = Wv[i * LD + a] * ma;
+            double inner = 0.0;
+            for (int b = 0; b < q; ++b) inner += w.Kt[a * LD + b] * Wv[i * LD + b] * (w.sq[b] * w.rp[b]);
+            acc += wa * inner;
+            acc0 += w.Kt[i * LD + a] * ma * ma;
+        }
+        w.ci[i] = acc;
+        w.tv[i] = acc0 * mi * mi;
+    }
+    // B/2
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, j = e - i * q;
+        if (j > i) continue;
+        double acc = 0.0;
+        for (int a = 0; a < q; ++a) acc += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
+        Bh[i * LD + j] = acc;
+        Bh[j * LD + i] = acc;
+    }
+    __syncthreads();
+    double c0 = 0.0;
+    for (int i = 0; i < q; ++i) c0 += w.tv[i];
+    // A = -hess = 1/2 (Q - ci - cj + c0) + B/2, lower triangle
+    const int npair = q * (q + 1) / 2;
+    for (int e = tid; e < npair; e += T) {
+        // unrank e -> (i >= j)
+        int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= e) ++i;
+        while (i * (i + 1) / 2 > e) --i;
+        const int j = e - i * (i + 1) / 2;
+        double Q = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double za = Wv[i * LD + a] * Wv[j * LD + a];
+            double inner = 0.5 * w.Kt[a * LD + a] * za;
+            for (int b = 0; b < a; ++b) inner += w.Kt[a * LD + b] * (Wv[i * LD + b] * Wv[j * LD + b]);
+            Q += za * inner;
+        }
+        Q *= 2.0;
+        const double val = 0.5 * (Q - w.ci[i] - w.ci[j] + c0) + Bh[i * LD + j];
+        w.H[i * LD + j] = val;
+    }
+    __syncthreads();
+    // in-place Cholesky of A (lower) and solve A step = grad
+    int fail = 0;
+    for (int k = 0; k < q; ++k) {
+        const double akk = w.H[k * LD + k];
+        if (!(akk > 0.0)) { fail = 1; break; }     // identical in every thread
+        const double piv = sqrt(akk);
+        __syncthreads();
+        if (tid == 0) w.H[k * LD + k] = piv;
+        for (int i = k + 1 + tid; i < q; i += T) w.H[i * LD + k] /= piv;
+        __syncthreads();
+        const int rem = q - k - 1;
+        for (int e = tid; e < rem * rem; e += T) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j <= i) w.H[i * LD + j] -= w.H[i * LD + k] * w.H[j * LD + k];
+        }
+        __syncthreads();
+    }
+    if (fail) return 1;
+    if (tid < q) w.step[tid] = w.grad[tid];
+    __syncthreads();
+    for (int k = 0; k < q; ++k) {          // forward: L y = grad
+        const double yk = w.step[k] / w.H[k * LD + k];
+        __syncthreads();
+        if (tid == k) w.step[k] = yk;
+        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
+        __syncthreads();
+    }
+    for (int k = q - 1; k >= 0; --k) {     // backward: L^T x = y
+        const double xk = w.step[k] / w.H[k * LD + k];
+        __syncthreads();
+        if (tid == k) w.step[k] = xk;
+        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
+        __syncthreads();
+    }
+    return 0;
+}
+
+// ---- full solve.  On entry w.S (symmetric) and w.dl are set.  On exit w.p holds the optimum and
+// the eigen-state (V, sq, R, rp, s) belongs to it.  Returns status; *g_out = max g. ---------------
+template <int T>
+__device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    // start: the closed-form q = 1 weights, shrunk into the simplex
+    if (tid < q) {
+        const double d = w.dl[tid], s2 = w.S[tid * LD + tid];
+        const double r = sqrt(s2 + d * d);
+        w.pn[tid] = (d >= 0.0) ? 0.5 * s2 / (r * (r + d)) : 0.5 * (r - d) / r;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < q; ++i) tot += w.pn[i];
+    __syncthreads();
+    if (tid < q) w.p[tid] = fmax(w.pn[tid] / (1.0 + tot), 1e-300);
+    __syncthreads();
+    int sweeps = 0, it = 0, status = 1;
+    double g = sdp_eval<T>(w, w.p, sweeps);
+    if (!(g > -INFINITY)) { *g_out = g; *iters_out = 0; return 2; }
+    for (it = 1; it <= SDP_MAX_NEWTON; ++it) {
+        if (sdp_newton_dir<T>(w)) { status = 2; break; }
+        double rel = 0.0, ssum = 0.0, dec = 0.0, psum = 0.0;
+        for (int i = 0; i < q; ++i) {
+            const double st = w.step[i];
+            rel = fmax(rel, fabs(st) / w.p[i]);
+            ssum += st; psum += w.p[i];
+            dec += w.grad[i] * st;
+        }
+        rel = fmax(rel, fabs(ssum) / (1.0 - psum));
+        if (!(rel == rel)) { status = 2; break; }
+        double t = rel < 0.9 ? 1.0 : 0.9 / rel;
+        const double slack = 1e-14 * (1.0 + fabs(g));
+        double gn = -INFINITY;
+        bool full = (t == 1.0);
+        for (int ls = 0; ls < 40; ++ls) {
+            __syncthreads();
+            if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
+            __syncthreads();
+            gn = sdp_eval<T>(w, w.pn, sweeps);
+            if (gn >= g + 1e-4 * t * dec - slack) break;
+            t *= 0.5; full = false;
+        }
+        __syncthreads();
+        if (tid < q) w.p[tid] = w.pn[tid];
+        __syncthreads();
+        g = gn;
+        if (!(g > -INFINITY)) { status = 2; break; }
+        if (full && rel < SDP_STEP_TOL) { status = 0; break; }
+    }
+    *g_out = g;
+    *iters_out = (it & 0xffff) | (sweeps << 16);
+    return status;
+}
+
+// ---- outputs from the final state ---------------------------------------------------------------
+// Writes N = B^-1 into w.H and c into w.ci, (N c) into w.tv; returns nu = c^T N c.
+// Needs w.V, w.s, w.sq, w.sv, w.R, w.rp of the optimum; `mu` in LDS.
+template <int T>
+__device__ double sdp_primal(const SdpWork& w, const double* mu) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    double sum = 0.0;
+    for (int i = 0; i < q; ++i) sum += w.p[i];
+    const double gam = 1.0 / (1.0 + sqrt(1.0 - sum));
+    double* U = w.X;
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        U[i * LD + a] = w.s[i] * w.V[i * LD + a] - gam * w.p[i] * w.sv[a];
+    }
+    if (tid < q) {     // c = mu + B p / 2 = mu + R (sq * rp)
+        double acc = 0.0;
+        for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * w.rp[a];
+        w.ci[tid] = mu[tid] + acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, j = e - i * q;
+        if (j > i) continue;
+        double acc = 0.0;
+        for (int a = 0; a < q; ++a) acc += U[i * LD + a] * U[j * LD + a] / w.sq[a];
+        w.H[i * LD + j] = 0.5 * acc;
+        w.H[j * LD + i] = 0.5 * acc;
+    }
+    __syncthreads();
+    if (tid < q) {
+        double acc = 0.0;
+        for (int j = 0; j < q; ++j) acc += w.H[tid * LD + j] * w.ci[j];
+        w.tv[tid] = acc;
+    }
+    __syncthreads();
+    double nu = 0.0;
+    for (int i = 0; i < q; ++i) nu += w.ci[i] * w.tv[i];
+    return nu;
+}

@@ -1,0 +1,200 @@
+"""Host-side handle around the C ABI: torch tensors for device memory and streams, nothing else.
+
+`DeviceGP` owns one `oei_model` (the factorised GP of one BO iteration) on one GPU and exposes
+the batched entry points with [B, q, d] candidate tensors.  The reference never evaluates more
+than one candidate batch at a time (bo.py:142-175); batching B candidates is what the GPU path adds.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+KERNEL_RBF = 0
+KERNEL_MATERN32 = 1
+FLOOR_NONE, FLOOR_SAFE, FLOOR_STOCK = 0, 1, 2
+
+STATUS_TEXT = {0: 'Solved', 1: 'Iteration limit', 2: 'Numerical breakdown', 3: 'Eigen-iteration limit'}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f64(x, device):
+    t = torch.as_tensor(x, dtype=torch.float64, device=device)
+    return t.contiguous()
+
+
+class DeviceGP:
+    """A GP regression model factorised once on the current GPU."""
+
+    def __init__(self, X, y, kernel_kind, variance, lengthscales, noise, floor_mode=None,
+                 device=None):
+        if not torch.cuda.is_available():
+            raise _lib.OeiError('no GPU visible: the OEI path has no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        assert X.ndim == 2 and X.shape[0] == y.shape[0]
+        self.n, self.dim = X.shape
+        ls = np.ascontiguousarray(np.atleast_1d(np.asarray(lengthscales, dtype=np.float64)))
+        if floor_mode is None:
+            floor_mode = FLOOR_NONE if kernel_kind == KERNEL_RBF else FLOOR_SAFE
+        self.kernel_kind, self.floor_mode = int(kernel_kind), int(floor_mode)
+        self.variance, self.lengthscales, self.noise = float(variance), ls, float(noise)
+        self.X_train, self.y_train = X, y
+        handle = ctypes.c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(lib.oei_model_create(ctypes.byref(handle), self.n, self.dim,
+                                       X.ctypes.data_as(ctypes.c_void_p),
+                                       y.ctypes.data_as(ctypes.c_void_p),
+                                       self.kernel_kind, self.floor_mode, self.variance,
+                                       ls.ctypes.data_as(ctypes.c_void_p), int(ls.size),
+                                       self.noise), 'oei_model_create')
+        self._h = handle
+        fmin = ctypes.c_double(0.0)
+        check(lib.oei_model_info(self._h, ctypes.byref(fmin), None, None), 'oei_model_info')
+        self.fmin = fmin.value
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            lib.oei_model_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def factor(self):
+        L = np.empty((self.n, self.n))
+        check(lib.oei_model_get_factor(self._h, L.ctypes.data_as(ctypes.c_void_p)), 'oei_model_get_factor')
+        return L
+
+    # ---- batched device API -----------------------------------------------------------------
+    def predict_f(self, X):
+        X = _dev_f64(X, self.device).reshape(-1, self.dim)
+        m = X.shape[0]
+        mean = torch.empty(m, dtype=torch.float64, device=self.device)
+        var = torch.empty(m, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.oei_predict_f(self._h, m, _ptr(X), _ptr(mean), _ptr(var), _stream()), 'oei_predict_f')
+        return mean, var
+
+    def _batch(self, X):
+        X = _dev_f64(X, self.device)
+        if X.dim() == 2:
+            X = X.unsqueeze(0)
+        assert X.dim() == 3 and X.shape[2] == self.dim, 'X must be [B, q, d]'
+        return X.contiguous()
+
+    def omega(self, X):
+        X = self._batch(X)
+        B, q, _ = X.shape
+        om = torch.empty((B, q + 1, q + 1), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.oei_omega_batched(self._h, B, q, _ptr(X), _ptr(om), _stream()), 'oei_omega_batched')
+        return om
+
+    def value_grad(self, X, want_flags=True):
+        """[B,q,d] -> value [B], grad [B,q,d], status int32 [B], flags int32 [B]."""
+        X = self._batch(X)
+        B, q, d = X.shape
+        value = torch.empty(B, dtype=torch.float64, device=self.device)
+        grad = torch.empty((B, q, d), dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        flags = torch.empty(B, dtype=torch.int32, device=self.device) if want_flags else None
+        with torch.cuda.device(self.device):
+            check(lib.oei_value_grad_batched(self._h, B, q, _ptr(X), _ptr(value), _ptr(grad),
+                                             _ptr(status), _ptr(flags), _stream()),
+                  'oei_value_grad_batched')
+        return value, grad, status, flags
+
+    def hessian(self, X):
+        X = self._batch(X)
+        B, q, d = X.shape
+        H = torch.empty((B, q * d, q * d), dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.oei_hessian_batched(self._h, B, q, _ptr(X), _ptr(H), _ptr(status), _stream()),
+                  'oei_hessian_batched')
+        return H, status
+
+    def domega(self, X):
+        X = self._batch(X)
+        B, q, d = X.shape
+        out = torch.empty((B, q + 1, q + 1, q * d), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.oei_domega_batched(self._h, B, q, _ptr(X), _ptr(out), _stream()), 'oei_domega_batched')
+        return out
+
+
+# ---- model-free entry points ------------------------------------------------------------------
+def sdp_batched(omega, fmin, want_Y=True, device=None):
+    """omega [B,k_,k_], fmin [B] or scalar -> value [B], M [B,k_,k_], Y [B,k_,k_,k_] or None,
+    status [B], iters [B] (device tensors)."""
+    if not torch.cuda.is_available():
+        raise _lib.OeiError('no GPU visible: the OEI path has no CPU fallback')
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    om = _dev_f64(omega, device)
+    if om.dim() == 2:
+        om = om.unsqueeze(0)
+    B, k_, _ = om.shape
+    fm = _dev_f64(fmin, device).reshape(-1)
+    if fm.numel() == 1 and B > 1:
+        fm = fm.expand(B).contiguous()
+    assert fm.numel() == B
+    value = torch.empty(B, dtype=torch.float64, device=device)
+    M = torch.empty((B, k_, k_), dtype=torch.float64, device=device)
+    Y = torch.empty((B, k_, k_, k_), dtype=torch.float64, device=device) if want_Y else None
+    status = torch.empty(B, dtype=torch.int32, device=device)
+    iters = torch.empty(B, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        check(lib.oei_sdp_batched(B, k_, _ptr(om), _ptr(fm), _ptr(value), _ptr(M), _ptr(Y),
+                                  _ptr(status), _ptr(iters), _stream()), 'oei_sdp_batched')
+    return value, M, Y, status, iters
+
+
+def solution_derivative_batched(M, Y, fmin, domega, want_dY=False, device=None):
+    """M [B,k_,k_], Y [B,k_,k_,k_], fmin [B], domega [B,k_,k_,K] -> dM [B,k_,k_,K] (, dY)."""
+    if not torch.cuda.is_available():
+        raise _lib.OeiError('no GPU visible: the OEI path has no CPU fallback')
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    M = _dev_f64(M, device)
+    Y = _dev_f64(Y, device)
+    dom = _dev_f64(domega, device)
+    if M.dim() == 2:
+        M, Y, dom = M.unsqueeze(0), Y.unsqueeze(0), dom.unsqueeze(0)
+    B, k_, _ = M.shape
+    K = dom.shape[3]
+    fm = _dev_f64(fmin, device).reshape(-1)
+    if fm.numel() == 1 and B > 1:
+        fm = fm.expand(B).contiguous()
+    dM = torch.empty((B, k_, k_, K), dtype=torch.float64, device=device)
+    dY = torch.empty((B, k_, k_, k_), dtype=torch.float64, device=device) if want_dY else None
+    status = torch.empty(B, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        check(lib.oei_solution_derivative_batched(B, k_, K, _ptr(M), _ptr(Y), _ptr(fm), _ptr(dom),
+                                                  _ptr(dM), _ptr(dY), _ptr(status), _stream()),
+              'oei_solution_derivative_batched')
+    return dM, dY, status
+
+
+def argmin(value, index_base=0):
+    """Device arg-min with ties to the lowest index -> (best_value [1], best_index int64 [1])."""
+    value = value.contiguous()
+    bv = torch.empty(1, dtype=torch.float64, device=value.device)
+    bi = torch.empty(1, dtype=torch.int64, device=value.device)
+    with torch.cuda.device(value.device):
+        check(lib.oei_argmin(int(value.numel()), _ptr(value), int(index_base), _ptr(bv), _ptr(bi),
+                             _stream()), 'oei_argmin')
+    return bv, bi

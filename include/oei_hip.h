@@ -1,0 +1,122 @@
+/*
+ * oei_hip.h -- C ABI of the MI355X (gfx950) implementation of the Optimistic Expected
+ * Improvement evaluation path.  All arithmetic is fp64.
+ *
+ * The reference has no FFI layer: its boundary is a set of Python callables
+ * (methods/oei.py, methods/sdp.py) whose arithmetic runs inside third-party native code
+ * (gpflow/TensorFlow kernels, SCS, MKL-Pardiso).  Each entry point below names the reference
+ * callable (file:line under the reference root) whose arithmetic it replaces; the Python shim in
+ * bayesian_optimization_amd/methods presents B=1 slices of them under the reference's names.
+ *
+ * Conventions
+ *   - return value: 0 = success, negative = error (see OEI_ERR_*); nothing throws.
+ *   - "host" pointers are ordinary process memory, "device" pointers are HIP device memory on the
+ *     device that was current when the model was created (or is current, for the model-free calls).
+ *   - the caller owns every input and output buffer; the library keeps internal scratch per model
+ *     handle (or per device for model-free calls) and grows it on demand.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     stream-ordered; they return once the work is enqueued unless stated otherwise.
+ *   - matrices are dense row-major.  k_ = q + 1.
+ *   - per-candidate `status`: 0 = converged, 1 = iteration limit reached, 2 = numerical breakdown
+ *     (Omega not positive definite, NaN), 3 = eigen-iteration limit.  Like the reference
+ *     (sdp.py:53-56: warn and continue) a non-zero status never aborts the batch.
+ */
+#ifndef OEI_HIP_H
+#define OEI_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OEI_OK            0
+#define OEI_ERR_ARG      -1   /* bad argument (null pointer, size out of range) */
+#define OEI_ERR_HIP      -2   /* a HIP runtime call failed; see oei_last_error() */
+#define OEI_ERR_NOT_PD   -3   /* K + noise*I is not positive definite */
+#define OEI_ERR_NO_DEVICE -4  /* no HIP device present */
+
+#define OEI_KERNEL_RBF       0   /* variance * exp(-r2/2)                  run.py:80 */
+#define OEI_KERNEL_MATERN32  1   /* variance * (1+sqrt3 r) exp(-sqrt3 r)   run.py:19-23,81 */
+
+#define OEI_FLOOR_NONE   0   /* r = sqrt(r2) */
+#define OEI_FLOOR_SAFE   1   /* r = sqrt(max(r2, 1e-40))   run.py:19-23 (SafeMatern32) */
+#define OEI_FLOOR_STOCK  2   /* r = sqrt(r2 + 1e-12)       tests/create_model.py:28 (stock Matern32) */
+
+#define OEI_MAX_Q   64       /* largest batch size q the kernels accept */
+#define OEI_MAX_DIM 32       /* largest input dimension d */
+
+typedef struct oei_model oei_model;   /* opaque GP model handle */
+
+/* Human-readable description of the last error on this thread (never NULL). */
+const char* oei_last_error(void);
+
+/* Library/ABI version, for the loader to check. */
+int oei_abi_version(void);
+
+/* ---- model lifecycle ---------------------------------------------------------------------------
+ * Replaces what gpflow's GPR recomputes inside every Session.run of the reference
+ * (oei.py:27,33,34,49,58: K = k(X,X)+noise*I, its Cholesky factor, L^-1 y) plus the fmin of
+ * oei.py:27,49 (minimum posterior MEAN at the training inputs).  Done once per model here.
+ * X_train [n,d] and y [n] are host pointers; lengthscales has `n_lengthscales` entries (1 or d,
+ * run.py:94 ARD flag).  Synchronous. */
+int oei_model_create(oei_model** out, int n, int d,
+                     const double* X_train, const double* y,
+                     int kernel_kind, int floor_mode, double variance,
+                     const double* lengthscales, int n_lengthscales, double noise);
+int oei_model_destroy(oei_model* m);
+/* fmin, n, d of a model (host outputs). */
+int oei_model_info(const oei_model* m, double* fmin, int* n, int* d);
+/* Copies the n x n lower Cholesky factor L of K + noise*I to a host buffer (diagnostics/tests). */
+int oei_model_get_factor(const oei_model* m, double* L_host);
+
+/* ---- GP posterior ------------------------------------------------------------------------------
+ * predict_f (gpflow GPR.predict_f, called at oei.py:27,49 and tests/test_derivatives.py:45):
+ * X device [m,d] -> mean device [m], var device [m] (marginal variances, noise NOT added). */
+int oei_predict_f(oei_model* m, int npts, const double* X, double* mean, double* var, void* stream);
+
+/* omega (oei.py:79-103): X device [B,q,d] -> omega device [B,k_,k_]. */
+int oei_omega_batched(oei_model* m, int B, int q, const double* X, double* omega, void* stream);
+
+/* ---- the SDP -----------------------------------------------------------------------------------
+ * sdp (sdp.py:11-67): omega device [B,k_,k_], fmin device [B] ->
+ *   value device [B] (= <Omega,M>, <= 0), M device [B,k_,k_],
+ *   Y device [B,k_,k_,k_] or NULL (the k_ dual matrices Y_i, sdp.py:236-247),
+ *   status device int[B], iters device int[B] (Newton iterations; sweeps in the high 16 bits).
+ * Independent of any GP model.  Requires omega[b] positive definite. */
+int oei_sdp_batched(int B, int k_, const double* omega, const double* fmin,
+                    double* value, double* M, double* Y, int* status, int* iters, void* stream);
+
+/* solution_derivative (sdp.py:159-206): the sensitivity of the SDP solution to K perturbations of
+ * Omega.  M [B,k_,k_], Y [B,k_,k_,k_], fmin [B], domega [B,k_,k_,K] -> dM [B,k_,k_,K]
+ * (and dY [B,k_,k_,k_] when K == 1 and dY != NULL, sdp.py:195-204).  All device pointers. */
+int oei_solution_derivative_batched(int B, int k_, int K, const double* M, const double* Y,
+                                    const double* fmin, const double* domega,
+                                    double* dM, double* dY, int* status, void* stream);
+
+/* ---- fused acquisition -------------------------------------------------------------------------
+ * acquisition (oei.py:19-39 without `project`, which stays on the host): X device [B,q,d] ->
+ * value device [B], grad device [B,q,d], status device int[B].  `flags` device int[B] or NULL
+ * receives 1 where `project` (oei.py:157-199) would remove a point of candidate b (a point within
+ * 1e-2 lengthscales of a training input in every coordinate, or two points equal after rounding
+ * X/l to two decimals); the host shim re-evaluates those candidates on the reduced point set. */
+int oei_value_grad_batched(oei_model* m, int B, int q, const double* X,
+                           double* value, double* grad, int* status, int* flags, void* stream);
+
+/* acquisition_hessian (oei.py:41-64, 105-135): X device [B,q,d] -> H device [B,q*d,q*d]. */
+int oei_hessian_batched(oei_model* m, int B, int q, const double* X,
+                        double* H, int* status, void* stream);
+
+/* domega (oei.py:125-135): X device [B,q,d] -> domega device [B,k_,k_,q*d]. */
+int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* domega, void* stream);
+
+/* ---- multistart selection ----------------------------------------------------------------------
+ * Local half of "keep the best start" (bo.py:158-161): arg-min over value[0..B) with ties to the
+ * lowest index.  Writes best_value (device double[1]) and best_index (device long long[1], offset
+ * by index_base).  The cross-rank exchange is a torch.distributed all_gather of the
+ * (value, index, X[q,d]) record on the host side. */
+int oei_argmin(int B, const double* value, long long index_base,
+               double* best_value, long long* best_index, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OEI_HIP_H */
