@@ -32,6 +32,8 @@ SIGNATURES = {
     'oei_value_grad_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
     'oei_hessian_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     'oei_domega_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    'oei_set_profiling': (ctypes.c_int, [vp, ctypes.c_int]),
+    'oei_get_stage_times': (ctypes.c_int, [vp, vp]),
     'oei_argmin': (ctypes.c_int, [ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp]),
 }
 

@@ -408,8 +408,16 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     const int d = m->d;
     const size_t rows = (size_t)B * q, rows_pad = round_up(rows, 64);
     const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q) * sizeof(double);
-    rc = cross_factor(m, X, rows, aux_bytes, st);              // ws1 = A
+    const bool prof = m->profile != 0;
+    rc = oei_ws_reserve(m, rows_pad, aux_bytes);
     if (rc) return rc;
+    if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[0], st));
+    rc = oei_launch_gram(m, X, rows, rows_pad, m->ws0, st);
+    if (rc) return rc;
+    if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[1], st));
+    rc = oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows_pad, m->npad, 1, st);   // ws1 = A
+    if (rc) return rc;
+    if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[2], st));
     double* p_buf = m->aux;
     double* M11_buf = m->aux + (size_t)B * q;
     const size_t lds2 = (sdp_work_doubles(q) + acq_extra_doubles(q, d)) * sizeof(double);
@@ -428,8 +436,10 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     OEI_HIP_CHECK(hipGetLastError());
     if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
         OEI_HIP_CHECK(hipMemsetAsync(m->ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
+    if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[3], st));
     rc = oei_launch_gemm_nt(m->ws0, m->LinvT, m->ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
     if (rc) return rc;
+    if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
     if (q <= 32) {
         if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
         hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
@@ -438,6 +448,24 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
         hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
     }
     OEI_HIP_CHECK(hipGetLastError());
+    if (prof) { OEI_HIP_CHECK(hipEventRecord(m->ev[5], st)); m->ev_valid = 1; }
+    return OEI_OK;
+}
+
+extern "C" int oei_set_profiling(oei_model* m, int on) {
+    if (!m) { oei_set_error("set_profiling: null model"); return OEI_ERR_ARG; }
+    if (on && !m->ev[0])
+        for (int i = 0; i < 6; ++i) OEI_HIP_CHECK(hipEventCreate(&m->ev[i]));
+    m->profile = on;
+    m->ev_valid = 0;
+    return OEI_OK;
+}
+
+extern "C" int oei_get_stage_times(oei_model* m, float* ms5) {
+    if (!m || !ms5) { oei_set_error("get_stage_times: null pointer"); return OEI_ERR_ARG; }
+    if (!m->ev_valid) { oei_set_error("get_stage_times: no profiled call recorded"); return OEI_ERR_ARG; }
+    OEI_HIP_CHECK(hipEventSynchronize(m->ev[5]));
+    for (int i = 0; i < 5; ++i) OEI_HIP_CHECK(hipEventElapsedTime(&ms5[i], m->ev[i], m->ev[i + 1]));
     return OEI_OK;
 }
 

@@ -51,6 +51,9 @@ struct oei_model {
     double* ws1;      // [rows, npad]
     size_t aux_bytes;
     double* aux;      // per-candidate state (p, M11, ...)
+    int profile;      // record stage events in value_grad
+    hipEvent_t ev[6];
+    int ev_valid;
 };
 
 // ---- device helpers ---------------------------------------------------------------------------

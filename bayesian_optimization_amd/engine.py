@@ -80,6 +80,15 @@ class DeviceGP:
         check(lib.oei_model_get_factor(self._h, L.ctypes.data_as(ctypes.c_void_p)), 'oei_model_get_factor')
         return L
 
+    def set_profiling(self, on):
+        check(lib.oei_set_profiling(self._h, int(bool(on))), 'oei_set_profiling')
+
+    def stage_times_ms(self):
+        """Durations (ms) of [gram, GEMM1, moments+SDP, GEMM2, gradient] of the last profiled call."""
+        ms = (ctypes.c_float * 5)()
+        check(lib.oei_get_stage_times(self._h, ctypes.cast(ms, ctypes.c_void_p)), 'oei_get_stage_times')
+        return [float(x) for x in ms]
+
     # ---- batched device API -----------------------------------------------------------------
     def predict_f(self, X):
         X = _dev_f64(X, self.device).reshape(-1, self.dim)

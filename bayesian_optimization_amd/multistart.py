@@ -1,0 +1,62 @@
+"""Sharded multistart evaluation and best-start selection.
+
+The reference runs its multistart loop sequentially on one candidate batch at a time and keeps the
+best one (bo.py:142-161).  Candidate batches are independent, so they shard over ranks with no
+data-path collective; the only exchange is one all-gather of a small per-rank record
+
+    (value: f64, global index: i64, X: f64[q*d])          976 bytes at q=20, d=6
+
+followed by a local arg-min with ties going to the lowest global index, so that every rank count
+selects the same start.  One process per GPU; the process group's backend is RCCL ("nccl") on GPUs
+and gloo in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous block partition of `total` candidates: [lo, hi) of `rank`."""
+    base, rem = divmod(total, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def make_record(best_value, best_index, X_best):
+    """Pack (value, index, X) into one float64 tensor; the int64 index travels bit-exactly."""
+    rec = torch.empty(2 + X_best.numel(), dtype=torch.float64, device=X_best.device)
+    rec[0] = best_value.reshape(())
+    rec[1:2] = best_index.reshape(1).to(torch.int64).view(torch.float64)
+    rec[2:] = X_best.reshape(-1)
+    return rec
+
+
+def select_best(rec, group=None):
+    """All-gather the per-rank records and return (value, index, X_flat) of the winner.
+    Without an initialised process group the local record wins."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        world = dist.get_world_size(group)
+        allrec = torch.empty((world, rec.numel()), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(allrec, rec.contiguous(), group=group)
+    else:
+        allrec = rec.reshape(1, -1)
+    values = allrec[:, 0]
+    indices = allrec[:, 1].contiguous().view(torch.int64)
+    # NaN values never win; ties -> lowest global index
+    values = torch.where(torch.isnan(values), torch.full_like(values, float('inf')), values)
+    vmin = values.min()
+    cand = torch.where(values == vmin, indices, torch.full_like(indices, torch.iinfo(torch.int64).max))
+    win = int(torch.argmin(cand))
+    return allrec[win, 0], indices[win], allrec[win, 2:]
+
+
+def evaluate_and_select(gp, X_local, index_base=0, group=None):
+    """Evaluate value+gradient of the local shard on the GPU, then pick the global best start.
+    Returns (value [B], grad [B,q,d], status [B], (best_value, best_index, best_X [q,d]))."""
+    from . import engine
+    value, grad, status, _ = gp.value_grad(X_local, want_flags=False)
+    bv, bi = engine.argmin(value, index_base)
+    local = torch.clamp(bi - index_base, min=0)
+    Xb = X_local.reshape(X_local.shape[0], -1).index_select(0, local.reshape(1)).reshape(-1)
+    rec = make_record(bv, bi, Xb)
+    best_value, best_index, best_X = select_best(rec, group)
+    return value, grad, status, (best_value, best_index, best_X.reshape(X_local.shape[1:]))

@@ -108,6 +108,14 @@ int oei_hessian_batched(oei_model* m, int B, int q, const double* X,
 /* domega (oei.py:125-135): X device [B,q,d] -> domega device [B,k_,k_,q*d]. */
 int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* domega, void* stream);
 
+/* ---- measurement ---------------------------------------------------------------------------------
+ * No counterpart in the reference (its only timing hook is a commented-out print, sdp.py:52).
+ * With profiling on, oei_value_grad_batched records HIP events on its stream around each of its
+ * five kernels; oei_get_stage_times waits for the last call and returns their durations in
+ * milliseconds: [0] gram, [1] GEMM Ks L^-T, [2] moments+SDP, [3] GEMM Z L^-1, [4] gradient. */
+int oei_set_profiling(oei_model* m, int on);
+int oei_get_stage_times(oei_model* m, float* ms5);
+
 /* ---- multistart selection ----------------------------------------------------------------------
  * Local half of "keep the best start" (bo.py:158-161): arg-min over value[0..B) with ties to the
  * lowest index.  Writes best_value (device double[1]) and best_index (device long long[1], offset
