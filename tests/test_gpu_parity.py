@@ -139,3 +139,34 @@ def test_argmin_ties(cuda):
     v = torch.tensor([3.0, -1.0, 2.0, -1.0, 5.0], dtype=torch.float64, device=cuda)
     bv, bi = argmin(v, index_base=100)
     assert bv.item() == -1.0 and bi.item() == 101
+
+
+@pytest.mark.parametrize('n,q', [(25, 3), (25, 8), (310, 20)])
+def test_solution_derivative_vs_dense_kkt(cuda, n, q):
+    """sdp.solution_derivative: the reduced sensitivity solve against a dense solve of the
+    reference's KKT system (sdp.py:159-234), for dOmega/dx directions and a generic direction
+    with dOmega[-1,-1] != 0; plus dY for a single direction (sdp.py:195-204)."""
+    from bayesian_optimization_amd import sdp_batched, solution_derivative_batched
+    om, dm = _mk(n)
+    rs = np.random.RandomState(17)
+    Xs = rs.uniform(-.5, .5, (q, 6))
+    omega = om.omega(Xs)
+    value, M, Y, status, _ = [t.cpu().numpy() for t in sdp_batched(omega, om.fmin)]
+    assert status[0] == 0
+    C = sdp_ref.create_C(q + 1, om.fmin)
+    dom = om.domega(Xs)
+    D = rs.randn(q + 1, q + 1)
+    D = D + D.T
+    dom = np.concatenate([dom, D[:, :, None]], axis=2)
+    dM_ref = sdp_ref.solution_derivative(M[0], list(Y[0]), C, dom)
+    dM, _, st = solution_derivative_batched(M, Y, om.fmin, dom[None])
+    dM = dM.cpu().numpy()[0]
+    assert st.cpu().numpy()[0] == 0
+    scale = np.abs(dM_ref).max(axis=(0, 1), keepdims=True)
+    assert (np.abs(dM - dM_ref) / scale).max() < 1e-6         # task bar on the Hessian: 1e-3
+    dM1_ref, dY_ref = sdp_ref.solution_derivative(M[0], list(Y[0]), C, D, return_dY=True)
+    dM1, dY1, _ = solution_derivative_batched(M, Y, om.fmin, D[None, :, :, None], want_dY=True)
+    dY1 = dY1.cpu().numpy()[0]
+    assert np.abs(dM1.cpu().numpy()[0, :, :, 0] - dM1_ref[:, :, 0]).max() < 1e-6 * np.abs(dM1_ref).max()
+    dYr = np.stack(dY_ref)
+    assert np.abs(dY1 - dYr).max() < 1e-6 * np.abs(dYr).max()
