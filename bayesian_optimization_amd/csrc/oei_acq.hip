@@ -17,7 +17,7 @@
 // xq [q][d] must already be in LDS.  Ac is a [q][CH+1] staging buffer, vc a [CH] one.
 template <int T>
 __device__ void posterior_moments(const SdpWork& w, const KernParams& kp, double noise, int n,
-                                  int npad, const double* __restrict__ Arows,
+                                  int npad, size_t astride, const double* __restrict__ Arows,
                                   const double* __restrict__ v, const double* xq, double* mu,
                                   double* Ac, double* vc) {
     const int tid = threadIdx.x;
@@ -45,7 +45,7 @@ __device__ void posterior_moments(const SdpWork& w, const KernParams& kp, double
         __syncthreads();
         for (int e = tid; e < q * CH; e += T) {
             const int a = e / CH, k = e - a * CH;
-            Ac[a * (CH + 1) + k] = Arows[(size_t)a * npad + c * CH + k];
+            Ac[a * (CH + 1) + k] = Arows[(size_t)a * astride + c * CH + k];
         }
         for (int k = tid; k < CH; k += T) vc[k] = v[c * CH + k];
         __syncthreads();
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     const int tid = threadIdx.x, b = blockIdx.x, k_ = q + 1, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
-    posterior_moments<T>(w, kp, noise, n, npad, A + (size_t)b * q * npad, v, xq, mu, Ac, vc);
+    posterior_moments<T>(w, kp, noise, n, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu, Ac, vc);
     double* om = omega + (size_t)b * k_ * k_;
     for (int e = tid; e < k_ * k_; e += T) {
         const int i = e / k_, j = e - i * k_;
@@ -121,6 +121,7 @@ template <int T>
 __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, double fmin, int n,
                                               int npad, int q, const double* __restrict__ Xq,
                                               const double* __restrict__ A,
+                                              size_t a_cand_stride, size_t a_row_stride,
                                               const double* __restrict__ v,
                                               double* __restrict__ value, int* __restrict__ status,
                                               double* __restrict__ p_out,
@@ -136,8 +137,8 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
     const int tid = threadIdx.x, b = blockIdx.x, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
-    const double* Arows = A + (size_t)b * q * npad;
-    posterior_moments<T>(w, kp, noise, n, npad, Arows, v, xq, mu, Ac, vc);
+    const double* Arows = A + (size_t)b * a_cand_stride;
+    posterior_moments<T>(w, kp, noise, n, npad, a_row_stride, Arows, v, xq, mu, Ac, vc);
     if (tid < q) w.dl[tid] = mu[tid] - fmin;
     __syncthreads();
     double g = 0.0;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
         __syncthreads();
         for (int e = tid; e < q * CH; e += T) {
             const int a = e / CH, k = e - a * CH;
-            Ac[a * (CH + 1) + k] = Arows[(size_t)a * npad + c * CH + k];
+            Ac[a * (CH + 1) + k] = Arows[(size_t)a * a_row_stride + c * CH + k];
         }
         __syncthreads();
         for (int e = tid; e < q * CH; e += T) {
@@ -365,6 +366,27 @@ static int set_lds(K kernel, size_t lds) {
     return OEI_OK;
 }
 
+// moments + SDP + Z for B candidates whose A rows sit at A + b*a_cand_stride + a*a_row_stride.
+int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
+                      size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
+                      double* p_buf, double* M11_buf, double* Z, hipStream_t st) {
+    const size_t lds2 = (sdp_work_doubles(q) + acq_extra_doubles(q, m->d)) * sizeof(double);
+    int rc;
+    if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
+        oei_set_error("stage2: q=%d exceeds the per-thread accumulator budget", q);
+        return OEI_ERR_ARG;
+    }
+    if (q <= 32) {
+        if ((rc = set_lds(k_stage2<64>, lds2))) return rc;
+        hipLaunchKernelGGL(k_stage2<64>, dim3(B), dim3(64), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z);
+    } else {
+        if ((rc = set_lds(k_stage2<256>, lds2))) return rc;
+        hipLaunchKernelGGL(k_stage2<256>, dim3(B), dim3(256), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z);
+    }
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
 extern "C" int oei_predict_f(oei_model* m, int npts, const double* X, double* mean, double* var,
                              void* stream) {
     if (!m || npts < 0 || (npts > 0 && (!X || !mean || !var))) { oei_set_error("predict_f: bad argument"); return OEI_ERR_ARG; }
@@ -420,20 +442,13 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[2], st));
     double* p_buf = m->aux;
     double* M11_buf = m->aux + (size_t)B * q;
-    const size_t lds2 = (sdp_work_doubles(q) + acq_extra_doubles(q, d)) * sizeof(double);
     const size_t ldsg = ((size_t)q * d + 2 * (size_t)q * q + q + (size_t)q * (CH + 1) + (size_t)CH * ((d + 1) | 1)) * sizeof(double);
     if (q * (d + 1) > ITEMS_MAX * (q <= 32 ? 64 : 256) || q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
         return OEI_ERR_ARG;
     }
-    if (q <= 32) {
-        if ((rc = set_lds(k_stage2<64>, lds2))) return rc;
-        hipLaunchKernelGGL(k_stage2<64>, dim3(B), dim3(64), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, m->ws1, m->v, value, status, p_buf, M11_buf, m->ws0);
-    } else {
-        if ((rc = set_lds(k_stage2<256>, lds2))) return rc;
-        hipLaunchKernelGGL(k_stage2<256>, dim3(B), dim3(256), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, m->ws1, m->v, value, status, p_buf, M11_buf, m->ws0);
-    }
-    OEI_HIP_CHECK(hipGetLastError());
+    rc = oei_launch_stage2(m, B, q, X, m->ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, m->ws0, st);
+    if (rc) return rc;
     if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
         OEI_HIP_CHECK(hipMemsetAsync(m->ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[3], st));

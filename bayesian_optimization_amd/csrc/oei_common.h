@@ -51,6 +51,8 @@ struct oei_model {
     double* ws1;      // [rows, npad]
     size_t aux_bytes;
     double* aux;      // per-candidate state (p, M11, ...)
+    size_t hs_bytes;  // Hessian-path scratch (Gram blocks, Z/W rows)
+    double* hs;
     int profile;      // record stage events in value_grad
     hipEvent_t ev[6];
     int ev_valid;
@@ -101,9 +103,14 @@ int oei_ws_reserve(oei_model* m, size_t rows, size_t aux_bytes);
 // MODE 0: kernel value; MODE 1..d: derivative of k(x_r, X_k) with respect to x_r[MODE-1].
 int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
                     double* Ks, hipStream_t st);
-// Kd[(r*d + l), k] = d k(x_r, X_k) / d x_r[l]
-int oei_launch_gram_deriv(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
-                          double* Kd, hipStream_t st);
+// Extended rows of the Hessian path: per candidate RP rows (value rows, derivative rows, y, zeros).
+int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int RP, double* out,
+                        hipStream_t st);
+int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
+                      size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
+                      double* p_buf, double* M11_buf, double* Z, hipStream_t st);
+// G_b = E_b E_b^T (lower block-triangle of 64x64 tiles), E [B*RP, npad], G [B, RP, RP].
+int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st);
 // C[r, j] = sum_k A[r, k] * Bm[j, k], all [*, npad] row-major; `lower` != 0 means Bm is lower
 // triangular (k <= j), else upper triangular (k >= j).
 int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,

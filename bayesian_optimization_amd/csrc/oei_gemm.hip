@@ -1,13 +1,15 @@
-// Cross-covariance (kernel Gram) generation and the fp64 MFMA GEMM that applies the shared
+// Cross-covariance (kernel Gram) generation and the fp64 MFMA GEMMs that apply the shared
 // triangular factor inverse to many candidate batches at once.
 //
-//   Ks[r, k] = k(x_r, X_k)                      gram kernel (VALU: sqrt/exp per entry)
+//   Ks[r, k] = k(x_r, X_k)                      gram kernels (VALU: sqrt/exp per entry)
 //   C[r, j]  = sum_k A[r, k] * Bm[j, k]         "NT" GEMM on v_mfma_f64_16x16x4_f64
 //
 // With Bm = L^-1 (lower) the GEMM gives A = Ks L^-T, i.e. the rows of (L^-1 k(X, x_r))^T that
 // gpflow obtains with a triangular solve per call (oei.py:86 -> GPR.build_predict).  With
 // Bm = L^-T (upper, stored row-major) it gives Z L^-1, the second solve of K^-1.  The K range of
 // each 64-column tile stops (starts) at the diagonal, so only the non-zero half is multiplied.
+// The same tile routine, batched over candidates with both operands taken from one row block,
+// forms the Gram matrices E_b E_b^T of the Hessian path.
 #include "oei_common.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -23,7 +25,6 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // once per block; stores are coalesced along k.
 #define GR_ROWS 32
 
-template <int DERIV>
 __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __restrict__ Xtrain,
                                               int n, int npad, const double* __restrict__ Xq,
                                               size_t rows, double* __restrict__ out) {
@@ -53,18 +54,8 @@ __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __res
             t += df * df * kp.inv_ls2[l];
         }
         double k0v, k1v, k2v;
-        const bool live = (r < rows) && (k < n);
-        if (DERIV == 0) {
-            kappa_eval<0>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
-            out[r * npad + k] = live ? kp.variance * k0v : 0.0;
-        } else {
-            kappa_eval<1>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
-            const double c = live ? 2.0 * kp.variance * k1v : 0.0;
-            for (int l = 0; l < d; ++l) {
-                double df = Qs[rr * d + l] - Xs[kk * d + l];
-                out[(r * d + l) * npad + k] = c * df * kp.inv_ls2[l];
-            }
-        }
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
+        out[r * npad + k] = ((r < rows) && (k < n)) ? kp.variance * k0v : 0.0;
     }
 }
 
@@ -72,43 +63,88 @@ int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t ro
                     double* Ks, hipStream_t st) {
     dim3 grid((unsigned)(rows_pad / GR_ROWS), m->npad / 64);
     size_t lds = (size_t)(64 + GR_ROWS) * m->d * sizeof(double);
-    hipLaunchKernelGGL(k_gram<0>, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks);
+    hipLaunchKernelGGL(k_gram, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }
 
-int oei_launch_gram_deriv(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
-                          double* Kd, hipStream_t st) {
-    dim3 grid((unsigned)(rows_pad / GR_ROWS), m->npad / 64);
+// Extended rows for the Hessian path.  Candidate b owns rows [b*RP, (b+1)*RP):
+//   r = a*(d+1)       -> k(x_a, X_k)
+//   r = a*(d+1)+1+l   -> d k(x_a, X_k) / d x_a[l]
+//   r = q*(d+1)       -> y_k            (becomes v = L^-1 y after the GEMM)
+//   larger r          -> 0
+__global__ __launch_bounds__(256) void k_gram_ext(KernParams kp, const double* __restrict__ Xtrain,
+                                                  const double* __restrict__ y, int n, int npad,
+                                                  const double* __restrict__ Xq, int q, int RP,
+                                                  double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int d = kp.d, dp = d + 1;
+    double* Xs = sm;                 // [64][d]
+    double* Qs = sm + 64 * d;        // [GR_ROWS][d]
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.y * 64;
+    const size_t r0 = (size_t)blockIdx.x * GR_ROWS;      // RP is a multiple of GR_ROWS
+    const size_t b = r0 / RP;
+    const int rl0 = (int)(r0 - b * RP);
+    for (int i = tid; i < 64 * d; i += 256) {
+        int k = k0 + i / d;
+        Xs[i] = (k < n) ? Xtrain[(size_t)k * d + (i % d)] : 0.0;
+    }
+    for (int i = tid; i < GR_ROWS * d; i += 256) {
+        const int rl = rl0 + i / d, a = rl / dp;
+        Qs[i] = (a < q) ? Xq[(b * q + a) * d + (i % d)] : 0.0;
+    }
+    __syncthreads();
+    const int kk = tid & 63;
+    const int k = k0 + kk;
+    for (int rr = tid >> 6; rr < GR_ROWS; rr += 4) {
+        const int rl = rl0 + rr, a = rl / dp, lp = rl - a * dp;
+        double val = 0.0;
+        if (a < q && k < n) {
+            double t = 0.0;
+            for (int l = 0; l < d; ++l) {
+                double df = Qs[rr * d + l] - Xs[kk * d + l];
+                t += df * df * kp.inv_ls2[l];
+            }
+            double k0v, k1v, k2v;
+            kappa_eval<1>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
+            if (lp == 0) val = kp.variance * k0v;
+            else val = 2.0 * kp.variance * k1v * (Qs[rr * d + lp - 1] - Xs[kk * d + lp - 1]) * kp.inv_ls2[lp - 1];
+        } else if (rl == q * dp && k < n) {
+            val = y[k];
+        }
+        out[(r0 + rr) * npad + k] = val;
+    }
+}
+
+int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int RP, double* out,
+                        hipStream_t st) {
+    dim3 grid((unsigned)((size_t)B * RP / GR_ROWS), m->npad / 64);
     size_t lds = (size_t)(64 + GR_ROWS) * m->d * sizeof(double);
-    hipLaunchKernelGGL(k_gram<1>, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Kd);
+    hipLaunchKernelGGL(k_gram_ext, grid, dim3(256), lds, st, m->kp, m->X, m->y, m->n, m->npad, Xq, q, RP, out);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
-// GEMM.  Block tile 64 x 64, K step 16, 4 waves; wave w owns rows [16w, 16w+16) x 64 columns as
-// four 16x16 accumulators.  Operand lane maps of v_mfma_f64_16x16x4_f64: lane l supplies
+// GEMM tile.  Block tile 64 x 64, K step 16, 4 waves; wave w owns rows [16w, 16w+16) x 64 columns
+// as four 16x16 accumulators.  Operand lane maps of v_mfma_f64_16x16x4_f64: lane l supplies
 // A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; accumulator register g of lane l is
 // D[row = (l >> 4) + 4 g][col = l & 15].
-__global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
-                                                 const double* __restrict__ Bm,
-                                                 double* __restrict__ C, int npad, int lower) {
-    __shared__ __attribute__((aligned(16))) double As[2][GM_BM * GM_LDS];
-    __shared__ __attribute__((aligned(16))) double Bs[2][GM_BN * GM_LDS];
+// Ag/Bg point at the first row of the two 64-row operand panels (leading dimension ld, K along
+// the row); Cg at the output tile (leading dimension ldc).
+__device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
+                                             const double* __restrict__ Bg0,
+                                             double* __restrict__ Cg, int ld, int ldc, int kbeg,
+                                             int kend, double* As, double* Bs) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int j0 = blockIdx.y * GM_BN;
-    const size_t r0 = (size_t)blockIdx.x * GM_BM;
-    const int kbeg = lower ? 0 : j0;
-    const int kend = lower ? (j0 + GM_BN) : npad;
-
     // staging map: thread t moves 4 consecutive doubles of row t/4
     const int srow = tid >> 2;
     const int scol = (tid & 3) * 4;
-    const double* Ag = A + (r0 + srow) * (size_t)npad + scol;
-    const double* Bg = Bm + (size_t)(j0 + srow) * npad + scol;
+    const double* Ag = Ag0 + (size_t)srow * ld + scol;
+    const double* Bg = Bg0 + (size_t)srow * ld + scol;
 
     double4_t acc[4];
 #pragma unroll
@@ -121,8 +157,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
     b1 = *reinterpret_cast<const double2*>(Bg + kbeg + 2);
     int buf = 0;
     for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
-        double* as = As[buf];
-        double* bs = Bs[buf];
+        double* as = As + buf * (GM_BM * GM_LDS);
+        double* bs = Bs + buf * (GM_BN * GM_LDS);
         as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
         as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
         bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
@@ -151,10 +187,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const size_t row = r0 + wave * 16 + rq + 4 * g;
-            C[row * npad + j0 + t * 16 + col] = acc[t][g];
+            const size_t row = wave * 16 + rq + 4 * g;
+            Cg[row * ldc + t * 16 + col] = acc[t][g];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
+                                                 const double* __restrict__ Bm,
+                                                 double* __restrict__ C, int npad, int lower) {
+    __shared__ __attribute__((aligned(16))) double As[2 * GM_BM * GM_LDS];
+    __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
+    const int j0 = blockIdx.y * GM_BN;
+    const size_t r0 = (size_t)blockIdx.x * GM_BM;
+    const int kbeg = lower ? 0 : j0;
+    const int kend = lower ? (j0 + GM_BN) : npad;
+    gemm_tile_nt(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
 }
 
 int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,
@@ -165,6 +213,29 @@ int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows
     }
     dim3 grid((unsigned)(rows_pad / GM_BM), npad / GM_BN);
     hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, A, Bm, C, npad, lower);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+// G_b = E_b E_b^T for every candidate: lower block-triangle of 64x64 tiles, tile index t of
+// blockIdx.y enumerates (I >= J).  E [B*RP, npad], G [B, RP, RP].
+__global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
+                                                  double* __restrict__ G, int RP, int npad) {
+    __shared__ __attribute__((aligned(16))) double As[2 * GM_BM * GM_LDS];
+    __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
+    const size_t b = blockIdx.x;
+    int t = blockIdx.y, I = 0;
+    while ((I + 1) * (I + 2) / 2 <= t) ++I;
+    const int J = t - I * (I + 1) / 2;
+    const double* Eb = E + b * (size_t)RP * npad;
+    gemm_tile_nt(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad,
+                 G + b * (size_t)RP * RP + (size_t)I * 64 * RP + J * 64, npad, RP, 0, npad, As, Bs);
+}
+
+int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st) {
+    const int nt = RP / 64;
+    dim3 grid((unsigned)B, nt * (nt + 1) / 2);
+    hipLaunchKernelGGL(k_gram_blk, grid, dim3(256), 0, st, E, G, RP, npad);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

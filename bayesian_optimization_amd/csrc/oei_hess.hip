@@ -161,14 +161,382 @@ extern "C" int oei_solution_derivative_batched(int B, int k_, int K, const doubl
     return OEI_OK;
 }
 
-extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, double* H,
-                                   int* status, void* stream) {
-    oei_set_error("hessian_batched: not built yet");
-    return OEI_ERR_ARG;
+// ================================================================================================
+// dOmega/dx tables from the Gram block G_b = E_b E_b^T
+// ================================================================================================
+// Row indices inside a candidate's block: A_a = a(d+1), T_(a,l) = a(d+1)+1+l, v = q(d+1).
+// G is stored as lower block-triangle of full 64x64 tiles, so G(r1, r2) is read at (max, min).
+__device__ __forceinline__ double gsym(const double* __restrict__ Gb, int RP, int r1, int r2) {
+    return (r1 >= r2) ? Gb[(size_t)r1 * RP + r2] : Gb[(size_t)r2 * RP + r1];
+}
+
+// mu[a], DS[a][l][b] = d Sigma_ab / d x_al (b == a: the full derivative of Sigma_aa),
+// dmuT[a][l] = d mu_a / d x_al, k1s[a][b] = 2 var kappa'(t_ab), k2s[a][b] = 4 var kappa''(t_ab).
+template <int T>
+__device__ void build_tables(const KernParams& kp, int q, const double* xq,
+                             const double* __restrict__ Gb, int RP, double* mu, double* DS,
+                             double* dmuT, double* k1s, double* k2s) {
+    const int tid = threadIdx.x, d = kp.d, dp = d + 1, vrow = q * dp;
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, b = e - a * q;
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - xq[b * d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        k1s[e] = (a == b) ? 0.0 : 2.0 * kp.variance * k1;
+        k2s[e] = (a == b) ? 0.0 : 4.0 * kp.variance * k2;
+    }
+    for (int a = tid; a < q; a += T) mu[a] = gsym(Gb, RP, vrow, a * dp);
+    for (int e = tid; e < q * d; e += T) {
+        const int a = e / d, l = e - a * d;
+        dmuT[e] = gsym(Gb, RP, vrow, a * dp + 1 + l);
+    }
+    __syncthreads();
+    for (int e = tid; e < q * d * q; e += T) {
+        const int a = e / (d * q), rem = e - a * d * q, l = rem / q, b = rem - l * q;
+        const double ta = gsym(Gb, RP, a * dp + 1 + l, b * dp);       // T_(a,l) . A_b
+        DS[e] = (a == b) ? -2.0 * ta
+                         : k1s[a * q + b] * (xq[a * d + l] - xq[b * d + l]) * kp.inv_ls2[l] - ta;
+    }
+    __syncthreads();
+}
+
+// ---- domega (oei.py:125-135): dense [k_, k_, q*d] from the tables --------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void k_domega(KernParams kp, int q, int RP,
+                                              const double* __restrict__ Xq,
+                                              const double* __restrict__ G,
+                                              double* __restrict__ domega) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int d = kp.d, qd = q * d, k_ = q + 1;
+    double* xq = sm;                    // [q*d]
+    double* mu = xq + qd;               // [q]
+    double* DS = mu + q;                // [q*d*q]
+    double* dmuT = DS + qd * q;         // [q*d]
+    double* k1s = dmuT + qd;            // [q*q]
+    double* k2s = k1s + q * q;          // [q*q]
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
+    __syncthreads();
+    build_tables<T>(kp, q, xq, G + b * (size_t)RP * RP, RP, mu, DS, dmuT, k1s, k2s);
+    double* out = domega + b * (size_t)k_ * k_ * qd;
+    for (size_t e = tid; e < (size_t)k_ * k_ * qd; e += T) {
+        const int ij = (int)(e / qd), al = (int)(e - (size_t)ij * qd);
+        const int i = ij / k_, j = ij - i * k_, a = al / d, l = al - a * d;
+        double val = 0.0;
+        if (i < q && j < q) {
+            if (i == j) { if (a == i) val = DS[(a * d + l) * q + a] + 2.0 * mu[a] * dmuT[al]; }
+            else {
+                if (a == i) val = DS[(a * d + l) * q + j] + dmuT[al] * mu[j];
+                else if (a == j) val = DS[(a * d + l) * q + i] + dmuT[al] * mu[i];
+            }
+        } else if (i < q) { if (a == i) val = dmuT[al]; }
+        else if (j < q) { if (a == j) val = dmuT[al]; }
+        out[e] = val;
+    }
+}
+
+// ================================================================================================
+// acquisition Hessian (oei.py:41-64, 105-123)
+// ================================================================================================
+// H[(a,l),(b,m)] = d2<Omega,M>/dx2 |_M  +  <dM_(a,l), dOmega_(b,m)>, with
+//   d2<Omega,M>/dx2 = 2 M11_ab dmu_al dmu_bm - 2 M11_ab T_al.T_bm - [a!=b] 2 M11_ab Hs_ab[l][m]
+//                     + [a==b] Dg_a[l][m],
+//   Dg_a = sum_k (p_a alpha_k - 2 W[a,k]) d2k(x_a,X_k)/dx_a^2 + 2 sum_{c!=a} M11_ac Hs_ac,
+//   Hs_ab[l][m] = d2k(x_a,x_b)/dx_al dx_am.
+#define HCH_MIN 16
+
+__host__ __device__ inline size_t hess_tab_doubles(int q, int d) {
+    const int dl = (d + 1) | 1;
+    size_t ds = (size_t)q * d * q, chunk = (size_t)2 * q * (HCH_MIN + 1) + (size_t)HCH_MIN * dl;
+    return ds > chunk ? ds : chunk;
+}
+
+__host__ __device__ inline size_t hess_lds_doubles(int q, int d) {
+    // SdpWork + mu[VL] + SensVec + xq + tables(DS | chunk) + dmuT + k1s + k2s + Dg + M11 + dNmu[VL]
+    return sdp_work_doubles(q) + (size_t)(1 + SENS_NVEC + 1) * sdp_vlen(q) + (size_t)q * d +
+           hess_tab_doubles(q, d) + (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double fmin, int n,
+                                            int npad, int q, int RP,
+                                            const double* __restrict__ Xtrain,
+                                            const double* __restrict__ alpha,
+                                            const double* __restrict__ Xq,
+                                            const double* __restrict__ G,
+                                            const double* __restrict__ Wm,
+                                            const double* __restrict__ p_in,
+                                            const double* __restrict__ M11_in,
+                                            double* __restrict__ Hout, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    SdpWork w;
+    sdp_carve(w, sm, q);
+    const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d, dl = (d + 1) | 1;
+    double* mu = sm + sdp_work_doubles(q);
+    SensVec sv;
+    sens_carve(sv, mu + VL, q);
+    double* dNmu = mu + VL + SENS_NVEC * VL;    // [VL]
+    double* xq = dNmu + VL;                     // [q*d]
+    double* tab = xq + qd;                      // DS [q*d*q], first used as chunk staging
+    double* dmuT = tab + hess_tab_doubles(q, d);
+    double* k1s = dmuT + qd;
+    double* k2s = k1s + q * q;
+    double* M11 = k2s + q * q;
+    double* Dg = M11 + q * q;                   // [q][d][d]
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const double* Gb = G + b * (size_t)RP * RP;
+    double* Hb = Hout + b * (size_t)qd * qd;
+    for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
+    for (int e = tid; e < q * q; e += T) M11[e] = M11_in[b * q * q + e];
+    if (tid < q) w.p[tid] = p_in[b * q + tid];
+    __syncthreads();
+
+    // ---- Dg pre-pass: chunks of training points staged in `tab` ---------------------------------
+    {
+        const size_t tabsz = hess_tab_doubles(q, d);
+        int ch = (int)((tabsz - 2 * q) / (2 * q + dl));
+        ch = (ch / 16) * 16;
+        if (ch > 64) ch = 64;
+        double* c1 = tab;                        // [q][ch+1]  coef * 2 var kappa'
+        double* c2 = c1 + q * (ch + 1);          // [q][ch+1]  coef * 4 var kappa''
+        double* Xc = c2 + q * (ch + 1);          // [ch][dl]
+        const int nsym = d * (d + 1) / 2;
+        const int nitems = q * nsym;             // per a: one item per (l <= m)
+        for (int e = tid; e < q * d * d; e += T) Dg[e] = 0.0;
+        const double* Wrows = Wm + b * (size_t)q * npad;
+        for (int c0 = 0; c0 < n; c0 += ch) {
+            __syncthreads();
+            for (int e = tid; e < ch * d; e += T) {
+                const int k = e / d, l = e - k * d, kg = c0 + k;
+                Xc[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
+            }
+            __syncthreads();
+            for (int e = tid; e < q * ch; e += T) {
+                const int a = e / ch, k = e - a * ch, kg = c0 + k;
+                double v1 = 0.0, v2 = 0.0;
+                if (kg < n) {
+                    double t = 0.0;
+                    for (int l = 0; l < d; ++l) {
+                        const double df = xq[a * d + l] - Xc[k * dl + l];
+                        t += df * df * kp.inv_ls2[l];
+                    }
+                    double k0, k1, k2;
+                    kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+                    const double coef = w.p[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg];
+                    v1 = coef * 2.0 * kp.variance * k1;
+                    v2 = coef * 4.0 * kp.variance * k2;
+                }
+                c1[a * (ch + 1) + k] = v1;
+                c2[a * (ch + 1) + k] = v2;
+            }
+            __syncthreads();
+            for (int e = tid; e < nitems; e += T) {
+                // entry (a, l, m2 >= l) and its mirror belong to this thread alone
+                const int a = e / nsym, it = e - a * nsym;
+                int l = 0, rem = it;
+                while (rem >= d - l) { rem -= d - l; ++l; }
+                const int m2 = l + rem;
+                double s = 0.0, s1 = 0.0;
+                const double xl = xq[a * d + l], xm = xq[a * d + m2];
+                for (int k = 0; k < ch; ++k) {
+                    s += c2[a * (ch + 1) + k] * (xl - Xc[k * dl + l]) * (xm - Xc[k * dl + m2]);
+                    s1 += c1[a * (ch + 1) + k];
+                }
+                s *= kp.inv_ls2[l] * kp.inv_ls2[m2];
+                if (m2 == l) s += s1 * kp.inv_ls2[l];       // 2 var kappa' delta_lm / ls_l^2
+                Dg[(a * d + l) * d + m2] += s;
+                if (m2 != l) Dg[(a * d + m2) * d + l] += s;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- tables, moments, state at the optimum --------------------------------------------------
+    build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
+    double* DS = tab;
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, c = e - a * q;
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - xq[c * d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        w.S[a * LD + c] = kp.variance * k0 - gsym(Gb, RP, a * dp, c * dp) + (a == c ? noise : 0.0);
+    }
+    if (tid < q) w.dl[tid] = mu[tid] - fmin;
+    // self-covariance part of Dg: 2 sum_{c != a} M11_ac Hs_ac
+    for (int e = tid; e < q * d * d; e += T) {
+        const int a = e / (d * d), rem = e - a * d * d, l = rem / d, m2 = rem - l * d;
+        double s = 0.0;
+        for (int c = 0; c < q; ++c) {
+            if (c == a) continue;
+            const double sdl = (xq[a * d + l] - xq[c * d + l]) * kp.inv_ls2[l];
+            const double sdm = (xq[a * d + m2] - xq[c * d + m2]) * kp.inv_ls2[m2];
+            s += M11[a * q + c] * (k2s[a * q + c] * sdl * sdm + (l == m2 ? k1s[a * q + c] * kp.inv_ls2[l] : 0.0));
+        }
+        Dg[e] += 2.0 * s;
+    }
+    __syncthreads();
+    int sweeps = 0;
+    const double g = sdp_eval<T>(w, w.p, sweeps);
+    int st = (g > -INFINITY) ? 0 : 2;
+    if (!st && sens_prepare<T>(w, mu, sv)) st = 2;
+    if (st) {
+        for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
+        if (tid == 0 && status) status[b] = 2;
+        return;
+    }
+
+    // ---- one sensitivity solve per direction, fused with the contraction ------------------------
+    for (int al = 0; al < qd; ++al) {
+        const int a = al / d, l = al - a * d;
+        __syncthreads();
+        if (tid < q) sv.dmu[tid] = (tid == a) ? dmuT[al] : 0.0;
+        for (int e = tid; e < q * q; e += T) {
+            const int i = e / q, j = e - i * q;
+            double val = 0.0;
+            if (i == a) val = DS[al * q + j];
+            else if (j == a) val = DS[al * q + i];
+            w.X[i * LD + j] = val;
+        }
+        const double dnu = sens_direction<T>(w, sv);
+        (void)dnu;
+        if (tid < q) {
+            double acc = 0.0;
+            for (int c = 0; c < q; ++c) acc += w.X[tid * LD + c] * mu[c];
+            dNmu[tid] = acc;
+        }
+        __syncthreads();
+        for (int bm = tid; bm < qd; bm += T) {
+            const int bb = bm / d, m2 = bm - bb * d;
+            // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
+            double acc = 0.0;
+            const double* dsrow = DS + (size_t)bm * q;
+            for (int c = 0; c < q; ++c) acc += w.X[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
+            double P = -acc + 2.0 * dmuT[bm] * (sv.w1[bb] + sv.w2[bb] - dNmu[bb]);
+            // d2<Omega,M>/dx2 at fixed M
+            const double tt = gsym(Gb, RP, a * dp + 1 + l, bb * dp + 1 + m2);
+            double inner = 2.0 * M11[a * q + bb] * (dmuT[al] * dmuT[bm] - tt);
+            if (a != bb) {
+                const double sdl = (xq[a * d + l] - xq[bb * d + l]) * kp.inv_ls2[l];
+                const double sdm = (xq[a * d + m2] - xq[bb * d + m2]) * kp.inv_ls2[m2];
+                inner -= 2.0 * M11[a * q + bb] *
+                         (k2s[a * q + bb] * sdl * sdm + (l == m2 ? k1s[a * q + bb] * kp.inv_ls2[l] : 0.0));
+            } else {
+                inner += Dg[(a * d + l) * d + m2];
+            }
+            Hb[(size_t)al * qd + bm] = inner + P;
+        }
+    }
+    if (tid == 0 && status) status[b] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+static int hs_reserve(oei_model* m, size_t bytes) {
+    if (bytes > m->hs_bytes) {
+        if (m->hs) OEI_HIP_CHECK(hipFree(m->hs));
+        m->hs = nullptr; m->hs_bytes = 0;
+        OEI_HIP_CHECK(hipMalloc(&m->hs, bytes));
+        m->hs_bytes = bytes;
+    }
+    return OEI_OK;
+}
+
+static int check_call(const oei_model* m, int B, int q, const void* X, const void* out, const char* who) {
+    if (!m) { oei_set_error("%s: null model", who); return OEI_ERR_ARG; }
+    if (B < 0 || q < 1 || q > OEI_MAX_Q) { oei_set_error("%s: B=%d q=%d out of range (1 <= q <= %d)", who, B, q, OEI_MAX_Q); return OEI_ERR_ARG; }
+    if (B > 0 && (!X || !out)) { oei_set_error("%s: null pointer", who); return OEI_ERR_ARG; }
+    return OEI_OK;
+}
+
+// gram_ext -> GEMM -> Gram blocks for candidates [0, Bc): E in ws1, G at m->hs.
+static int hess_front(oei_model* m, int Bc, int q, const double* X, int RP, size_t extra_bytes,
+                      hipStream_t st) {
+    const size_t rows = (size_t)Bc * RP;
+    int rc = oei_ws_reserve(m, rows, ((size_t)Bc * q + (size_t)Bc * q * q) * sizeof(double));
+    if (rc) return rc;
+    const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
+    if ((rc = hs_reserve(m, gbytes + extra_bytes))) return rc;
+    if ((rc = oei_launch_gram_ext(m, X, Bc, q, RP, m->ws0, st))) return rc;
+    if ((rc = oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows, m->npad, 1, st))) return rc;
+    return oei_launch_gram_blk(m->ws1, m->hs, Bc, RP, m->npad, st);
 }
 
 extern "C" int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* domega,
                                   void* stream) {
-    oei_set_error("domega_batched: not built yet");
-    return OEI_ERR_ARG;
+    int rc = check_call(m, B, q, X, domega, "domega_batched");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int d = m->d, qd = q * d, k_ = q + 1;
+    const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
+    const size_t lds = ((size_t)2 * qd + q + (size_t)qd * q + 2 * (size_t)q * q) * sizeof(double);
+    const int chunk = 512;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = (B - b0 < chunk) ? B - b0 : chunk;
+        const double* Xc = X + (size_t)b0 * qd;
+        if ((rc = hess_front(m, Bc, q, Xc, RP, 0, st))) return rc;
+        double* out = domega + (size_t)b0 * k_ * k_ * qd;
+        if (q <= 32) {
+            if ((rc = set_lds_attr(k_domega<64>, lds))) return rc;
+            hipLaunchKernelGGL(k_domega<64>, dim3(Bc), dim3(64), lds, st, m->kp, q, RP, Xc, m->hs, out);
+        } else {
+            if ((rc = set_lds_attr(k_domega<256>, lds))) return rc;
+            hipLaunchKernelGGL(k_domega<256>, dim3(Bc), dim3(256), lds, st, m->kp, q, RP, Xc, m->hs, out);
+        }
+        OEI_HIP_CHECK(hipGetLastError());
+    }
+    return OEI_OK;
+}
+
+extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, double* H,
+                                   int* status, void* stream) {
+    int rc = check_call(m, B, q, X, H, "hessian_batched");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int d = m->d, qd = q * d, npad = m->npad;
+    const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
+    const size_t lds = hess_lds_doubles(q, d) * sizeof(double);
+    const int chunk = 512;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int Bc = (B - b0 < chunk) ? B - b0 : chunk;
+        const double* Xc = X + (size_t)b0 * qd;
+        const size_t zrows = round_up_sz((size_t)Bc * q, 64);
+        const size_t zbytes = zrows * npad * sizeof(double);
+        const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
+        if ((rc = hess_front(m, Bc, q, Xc, RP, 2 * zbytes + Bc * sizeof(double) + Bc * sizeof(int), st))) return rc;
+        double* Zb = m->hs + gbytes / sizeof(double);
+        double* Wb = Zb + zrows * npad;
+        double* valb = Wb + zrows * npad;
+        int* stb = reinterpret_cast<int*>(valb + Bc);
+        double* p_buf = m->aux;
+        double* M11_buf = m->aux + (size_t)Bc * q;
+        OEI_HIP_CHECK(hipMemsetAsync(Zb, 0, zbytes, st));
+        // A rows of candidate b: E + b*RP*npad + a*(d+1)*npad
+        if ((rc = oei_launch_stage2(m, Bc, q, Xc, m->ws1, (size_t)RP * npad, (size_t)(d + 1) * npad,
+                                    valb, stb, p_buf, M11_buf, Zb, st))) return rc;
+        if ((rc = oei_launch_gemm_nt(Zb, m->LinvT, Wb, zrows, npad, 0, st))) return rc;
+        double* Hc = H + (size_t)b0 * qd * qd;
+        int* sc = status ? status + b0 : nullptr;
+        if (q <= 32) {
+            if ((rc = set_lds_attr(k_hess<64>, lds))) return rc;
+            hipLaunchKernelGGL(k_hess<64>, dim3(Bc), dim3(64), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
+        } else {
+            if ((rc = set_lds_attr(k_hess<256>, lds))) return rc;
+            hipLaunchKernelGGL(k_hess<256>, dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
+        }
+        OEI_HIP_CHECK(hipGetLastError());
+    }
+    return OEI_OK;
 }

@@ -246,7 +246,7 @@ static void model_free(oei_model* m) {
     if (!m) return;
     hipFree(m->X); hipFree(m->L); hipFree(m->Linv); hipFree(m->LinvT);
     hipFree(m->v); hipFree(m->alpha); hipFree(m->y);
-    hipFree(m->ws0); hipFree(m->ws1); hipFree(m->aux);
+    hipFree(m->ws0); hipFree(m->ws1); hipFree(m->aux); hipFree(m->hs);
     if (m->ev[0]) for (int i = 0; i < 6; ++i) hipEventDestroy(m->ev[i]);
     delete m;
 }

@@ -170,3 +170,33 @@ def test_solution_derivative_vs_dense_kkt(cuda, n, q):
     assert np.abs(dM1.cpu().numpy()[0, :, :, 0] - dM1_ref[:, :, 0]).max() < 1e-6 * np.abs(dM1_ref).max()
     dYr = np.stack(dY_ref)
     assert np.abs(dY1 - dYr).max() < 1e-6 * np.abs(dYr).max()
+
+
+@pytest.mark.parametrize('n,q,kind,fm', [(25, 3, ogp.KERNEL_MATERN32, 1), (70, 7, ogp.KERNEL_RBF, 0),
+                                          (310, 20, ogp.KERNEL_MATERN32, 2)])
+def test_domega(cuda, n, q, kind, fm):
+    om, dm = _mk(n, kind=kind, floor_mode=fm)
+    Xs = np.random.RandomState(19).uniform(-.5, .5, (3, q, 6))
+    got = dm.domega(Xs).cpu().numpy()
+    for b in range(3):
+        ref = om.domega(Xs[b])
+        assert np.abs(got[b] - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('n,q,kind,fm', [(25, 3, ogp.KERNEL_MATERN32, 1), (70, 5, ogp.KERNEL_RBF, 0),
+                                          (310, 20, ogp.KERNEL_MATERN32, 1)])
+def test_hessian_vs_oracle(cuda, n, q, kind, fm):
+    """acquisition_hessian: the fused HIP pipeline against the oracle's restatement of
+    oei.py:41-64 (dense KKT sensitivity + closed-form chain rule).  Task bar: 1e-3 on entries."""
+    om, dm = _mk(n, kind=kind, floor_mode=fm)
+    oracle = ooei.OEIOracle(om)
+    B = 2
+    Xs = np.random.RandomState(23).uniform(-.5, .5, (B, q, 6))
+    H, status = dm.hessian(Xs)
+    H = H.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for b in range(B):
+        Href = oracle.acquisition_hessian(Xs[b].ravel())
+        scale = np.abs(Href).max()
+        assert np.abs(H[b] - H[b].T).max() <= 1e-8 * scale
+        assert np.abs(H[b] - Href).max() <= 1e-6 * scale, np.abs(H[b] - Href).max() / scale
