@@ -35,8 +35,9 @@ def select_best(rec, group=None):
     Without an initialised process group the local record wins."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
-        allrec = torch.empty((world, rec.numel()), dtype=rec.dtype, device=rec.device)
-        dist.all_gather_into_tensor(allrec, rec.contiguous(), group=group)
+        flat = torch.empty(world * rec.numel(), dtype=rec.dtype, device=rec.device)
+        dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)
+        allrec = flat.reshape(world, rec.numel())
     else:
         allrec = rec.reshape(1, -1)
     values = allrec[:, 0]

@@ -1,0 +1,91 @@
+"""Generates the golden fixtures of tests/golden with the CPU oracle.
+
+    python tests/golden/make_golden.py
+
+The reference stores no expected outputs for this path and its solvers cannot be run here, so
+these vectors are produced by the oracle (the reference's formulation solved to machine precision)
+and each one is certified before it is written: KKT residuals of the SDP below 1e-9 and
+finite-difference agreement of gradient and Hessian.  Inputs are regenerable: the SDP instances
+are the reference's own test inputs (tests/test_sdp.py:45-62, legacy numpy seed 0); the GP models
+follow oracle/hart6.make_model (hart6 on [-1/2,1/2]^6, Matern-3/2, variance 1, lengthscale 0.5,
+noise 1e-6, normalised outputs, training design RandomState(0)).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import gp as ogp, hart6, oei as ooei, sdp_ref  # noqa: E402
+
+
+def cert_max(cert):
+    return max(v for k, v in cert.items() if k not in ('pobj', 'dobj'))
+
+
+def ref_sdp_inputs():
+    np.random.seed(0)
+    k = 5
+    out = []
+    for _ in range(10):
+        tmp = np.random.randn(k, k)
+        sigma = tmp.dot(tmp.T) + 0.01 * np.eye(k)
+        mu = np.random.randn(k, 1)
+        omega = np.zeros((k + 1, k + 1))
+        omega[0:k, 0:k] = sigma + mu.dot(mu.T)
+        omega[-1, 0:k] = mu.flatten()
+        omega[0:k, -1] = mu.flatten()
+        omega[-1, -1] = 1
+        fmin = np.random.randn(1)
+        out.append((omega, float(fmin[0])))
+    return out
+
+
+def main():
+    inst = ref_sdp_inputs()
+    om = np.stack([o for o, _ in inst])
+    fm = np.array([f for _, f in inst])
+    vals, Ms, Ys = [], [], []
+    for o, f in inst:
+        v, M, Y, _ = sdp_ref.sdp_exact(o, f)
+        assert cert_max(sdp_ref.kkt_certificate(o, f, M, Y)) < 1e-9
+        vals.append(v), Ms.append(M), Ys.append(np.stack(Y))
+    np.savez_compressed(os.path.join(HERE, 'sdp_reference_inputs.npz'), omega=om, fmin=fm,
+                        value=np.array(vals), M=np.stack(Ms), Y=np.stack(Ys))
+    print('sdp_reference_inputs: values', np.round(vals, 6))
+
+    for n, q, seed in [(10, 1, 101), (10, 3, 102), (25, 3, 103), (25, 8, 104), (310, 20, 105)]:
+        model = hart6.make_model(n)
+        orc = ooei.OEIOracle(model)
+        X = np.random.RandomState(seed).uniform(-0.5, 0.5, (q, 6))
+        assert len(orc.project(X)[0]) == q
+        omega = model.omega(X)
+        value, M, Y, C = sdp_ref.sdp_exact(omega, model.fmin)
+        assert cert_max(sdp_ref.kkt_certificate(omega, model.fmin, M, Y)) < 1e-9
+        _, grad = model.inner_and_grad(X, M)
+        hess = orc.acquisition_hessian(X.ravel())
+        # finite-difference certification of gradient (value) and Hessian (gradient)
+        h = 1e-5
+        x0 = X.ravel()
+        k = min(6, x0.size)
+        for j in range(k):
+            e = np.zeros_like(x0)
+            e[j] = h
+            vp = orc.acquisition(x0 + e)
+            vm = orc.acquisition(x0 - e)
+            assert abs((vp[0][0] - vm[0][0]) / (2 * h) - grad.ravel()[j]) < 1e-6 * (1 + np.abs(grad).max())
+            assert np.abs((vp[1] - vm[1]) / (2 * h) - hess[j]).max() < 1e-5 * (1 + np.abs(hess).max())
+        out = dict(n=n, q=q, X_train=model.X, y_train=model.y, variance=1.0, lengthscale=0.5,
+                   noise=model.noise, fmin=model.fmin, X=X, omega=omega, value=value, M=M,
+                   gradient=grad.ravel(), hessian=hess)
+        if q <= 8:
+            out['domega'] = model.domega(X)
+            out['dM'] = sdp_ref.solution_derivative(M, Y, C, out['domega'])
+        np.savez_compressed(os.path.join(HERE, 'oei_n%d_q%d.npz' % (n, q)), **out)
+        print('oei_n%d_q%d: value %.12f' % (n, q, value))
+
+
+if __name__ == '__main__':
+    main()

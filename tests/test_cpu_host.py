@@ -1,0 +1,155 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, argument
+validation works without a GPU, the sharding / best-start selection logic runs under gloo with
+world_size 2.  No compute call is made on a GPU here."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'oei_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(oei_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bayesian_optimization_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 14
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), 'missing export: ' + name
+    # and the binding covers the same set
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib.oei_abi_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_without_gpu():
+    from bayesian_optimization_amd._lib import lib
+    null = ctypes.c_void_p(0)
+    # empty batches succeed without touching a device
+    assert lib.oei_sdp_batched(0, 5, null, null, null, null, null, null, null, null) == 0
+    # out-of-range sizes and null pointers are rejected with OEI_ERR_ARG and a message
+    assert lib.oei_sdp_batched(4, 1, null, null, null, null, null, null, null, null) == -1
+    assert lib.oei_sdp_batched(4, 200, null, null, null, null, null, null, null, null) == -1
+    assert lib.oei_sdp_batched(4, 5, null, null, null, null, null, null, null, null) == -1
+    assert b'null' in lib.oei_last_error()
+    assert lib.oei_value_grad_batched(null, 1, 3, null, null, null, null, null, null) == -1
+    assert lib.oei_hessian_batched(null, 1, 3, null, null, null, null) == -1
+    assert lib.oei_solution_derivative_batched(2, 5, 0, null, null, null, null, null, null, null, null) == -1
+    handle = ctypes.c_void_p(0)
+    X = np.zeros((4, 2))
+    y = np.zeros(4)
+    ls = np.ones(1)
+    rc = lib.oei_model_create(ctypes.byref(handle), 4, 2, X.ctypes.data_as(ctypes.c_void_p),
+                              y.ctypes.data_as(ctypes.c_void_p), 7, 0, 1.0,
+                              ls.ctypes.data_as(ctypes.c_void_p), 1, 1e-6)
+    assert rc == -1 and b'kernel' in lib.oei_last_error()
+    if not torch.cuda.is_available():
+        rc = lib.oei_model_create(ctypes.byref(handle), 4, 2, X.ctypes.data_as(ctypes.c_void_p),
+                                  y.ctypes.data_as(ctypes.c_void_p), 1, 1, 1.0,
+                                  ls.ctypes.data_as(ctypes.c_void_p), 1, 1e-6)
+        assert rc == -4          # OEI_ERR_NO_DEVICE: the product path fails loudly without a GPU
+
+
+def test_product_path_has_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from bayesian_optimization_amd import DeviceGP, sdp_batched
+    from bayesian_optimization_amd._lib import OeiError
+    with pytest.raises(OeiError):
+        DeviceGP(np.zeros((4, 2)), np.zeros(4), 1, 1.0, [1.0], 1e-6)
+    with pytest.raises(OeiError):
+        sdp_batched(np.eye(3)[None], np.zeros(1))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'bayesian_optimization_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.cuh', '.h')):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', text, flags=re.M), f
+
+
+def test_shard_bounds_cover_everything():
+    from bayesian_optimization_amd.multistart import shard_bounds
+    for total, world in [(65536, 8), (4096, 1), (10, 4), (7, 8)]:
+        spans = [shard_bounds(total, world, r) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_shim_helpers_pack_unpack_and_C():
+    from bayesian_optimization_amd.methods import sdp as msdp
+    from oracle import sdp_ref
+    Z = np.random.RandomState(1).randn(5, 5)
+    Z = Z + Z.T
+    assert np.array_equal(msdp.pack(Z, 5), sdp_ref.pack(Z))
+    assert np.allclose(msdp.unpack(msdp.pack(Z, 5), 5), Z)
+    C1, C2 = msdp.create_C(4, np.array([0.3])), sdp_ref.create_C(4, 0.3)
+    assert all(np.array_equal(a, b) for a, b in zip(C1, C2))
+    msdp.reset_warm_starting()
+    assert len(msdp.past_omegas) == 0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _select_worker(rank, world, port, total, q, d, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from bayesian_optimization_amd import multistart
+    rs = np.random.RandomState(7)
+    values = torch.as_tensor(rs.randn(total))
+    values[5] = values[total - 3] = values.min() - 1.0       # a tie across ranks
+    X = torch.as_tensor(rs.rand(total, q, d))
+    lo, hi = multistart.shard_bounds(total, world, rank)
+    local = values[lo:hi]
+    li = int(torch.argmin(local))                            # first minimum = lowest index
+    rec = multistart.make_record(local[li], torch.tensor(lo + li), X[lo + li])
+    v, i, xb = multistart.select_best(rec)
+    torch.save({'v': float(v), 'i': int(i), 'x': xb.clone()}, os.path.join(out_dir, 'r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_select_best_gloo_world2(tmp_path):
+    """Sharded arg-min with one all-gather: every rank picks the same start, the one a single rank
+    would pick, with ties going to the lowest global index."""
+    total, q, d = 64, 3, 2
+    port = _free_port()
+    mp.spawn(_select_worker, args=(2, port, total, q, d, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'r0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'r1.pt'))
+    rs = np.random.RandomState(7)
+    values = rs.randn(total)
+    values[5] = values[total - 3] = values.min() - 1.0
+    X = rs.rand(total, q, d)
+    assert r0['i'] == r1['i'] == 5
+    assert r0['v'] == r1['v'] == values[5]
+    assert np.array_equal(r0['x'].numpy(), X[5].ravel()) and torch.equal(r0['x'], r1['x'])
+
+
+def test_select_best_single_process_handles_nan():
+    from bayesian_optimization_amd import multistart
+    rec = multistart.make_record(torch.tensor(float('nan')), torch.tensor(3), torch.zeros(4))
+    v, i, x = multistart.select_best(rec)
+    assert int(i) == 3
