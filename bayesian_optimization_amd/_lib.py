@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'liboei_hip.so')
+LIB_PATH = os.environ.get('OEI_LIB_OVERRIDE') or os.path.join(_HERE, 'liboei_hip.so')   # override: diagnostic builds only
 ABI_VERSION = 1
 
 c_double_p = ctypes.POINTER(ctypes.c_double)

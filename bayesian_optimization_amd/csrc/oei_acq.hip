@@ -81,9 +81,12 @@ __device__ void posterior_moments(const SdpWork& w, const KernParams& kp, double
     __syncthreads();
 }
 
-__host__ __device__ inline size_t acq_extra_doubles(int q, int d) {
-    // mu[q+2] + xq[q*d] + Ac[q*(CH+1)] + vc[CH]
-    return (size_t)(q + 2) + (size_t)q * d + (size_t)q * (CH + 1) + CH;
+// LDS of the per-candidate kernels: the solver region (with the A-row staging buffers Ac [q][CH+1]
+// and vc [CH] overlaid on the solver's scratch matrices, which are idle while rows are staged),
+// then mu [q+2] and xq [q*d].
+__host__ __device__ inline size_t acq_stage_doubles(int q) { return (size_t)q * (CH + 1) + CH; }
+__host__ __device__ inline size_t acq_lds_doubles(int q, int d) {
+    return sdp_region_doubles(q, acq_stage_doubles(q)) + (size_t)(q + 2) + (size_t)q * d;
 }
 
 // ---- omega (oei.py:79-96) ------------------------------------------------------------------------
@@ -96,9 +99,9 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q);
-    double* mu = sm + sdp_work_doubles(q);
+    double* mu = sm + sdp_region_doubles(q, acq_stage_doubles(q));
     double* xq = mu + q + 2;
-    double* Ac = xq + q * kp.d;
+    double* Ac = w.X;
     double* vc = Ac + q * (CH + 1);
     const int tid = threadIdx.x, b = blockIdx.x, k_ = q + 1, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
@@ -130,9 +133,9 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q);
-    double* mu = sm + sdp_work_doubles(q);
+    double* mu = sm + sdp_region_doubles(q, acq_stage_doubles(q));
     double* xq = mu + q + 2;
-    double* Ac = xq + q * kp.d;
+    double* Ac = w.X;
     double* vc = Ac + q * (CH + 1);
     const int tid = threadIdx.x, b = blockIdx.x, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
         const int i = e / q, j = e - i * q;
         M11_out[(size_t)b * q * q + e] = -w.H[i * LD + j];
     }
-    // Z[a, k] = sum_b M11[a, b] A[b, k]
+    // Z[a, k] = sum_b M11[a, b] A[b, k]   (staging overwrites solver scratch; only w.H = N is live)
     const int nchunks = npad / CH;
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();
@@ -370,7 +373,7 @@ static int set_lds(K kernel, size_t lds) {
 int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
                       size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
                       double* p_buf, double* M11_buf, double* Z, hipStream_t st) {
-    const size_t lds2 = (sdp_work_doubles(q) + acq_extra_doubles(q, m->d)) * sizeof(double);
+    const size_t lds2 = acq_lds_doubles(q, m->d) * sizeof(double);
     int rc;
     if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("stage2: q=%d exceeds the per-thread accumulator budget", q);
@@ -408,7 +411,7 @@ extern "C" int oei_omega_batched(oei_model* m, int B, int q, const double* X, do
     hipStream_t st = (hipStream_t)stream;
     rc = cross_factor(m, X, (size_t)B * q, 0, st);
     if (rc) return rc;
-    const size_t lds = (sdp_work_doubles(q) + acq_extra_doubles(q, m->d)) * sizeof(double);
+    const size_t lds = acq_lds_doubles(q, m->d) * sizeof(double);
     if (q <= 32) {
         if ((rc = set_lds(k_omega<64>, lds))) return rc;
         hipLaunchKernelGGL(k_omega<64>, dim3(B), dim3(64), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);

@@ -55,8 +55,9 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
     }
     __syncthreads();
     int sweeps = 0;
-    const double g = sdp_eval<T>(w, w.p, sweeps);
-    int st = (g > -INFINITY) ? 0 : 2;
+    int st = sdp_factor<T>(w) ? 2 : 0;
+    const double g = st ? -INFINITY : sdp_eval<T>(w, w.p, sweeps, false);
+    if (!(g > -INFINITY)) st = 2;
     if (!st && sens_prepare<T>(w, mu, sv)) st = 2;
     if (st) {
         for (size_t e = tid; e < (size_t)k_ * k_ * K; e += T) dM[(size_t)b * k_ * k_ * K + e] = NAN;
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
     }
     __syncthreads();
     int sweeps = 0;
-    const double g = sdp_eval<T>(w, w.p, sweeps);
-    int st = (g > -INFINITY) ? 0 : 2;
+    int st = sdp_factor<T>(w) ? 2 : 0;
+    const double g = st ? -INFINITY : sdp_eval<T>(w, w.p, sweeps, false);
+    if (!(g > -INFINITY)) st = 2;
     if (!st && sens_prepare<T>(w, mu, sv)) st = 2;
     if (st) {
         for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;

@@ -33,6 +33,16 @@
 #define SDP_JACOBI_TOL 1e-15
 #define SDP_STEP_TOL 1e-7
 
+// Diagnostic build only (-DOEI_SDP_TIMING): cycle counters per solver phase in w.scal[0..3]
+// (set-up of an evaluation, Jacobi, rest of the evaluation, Newton direction).
+#ifdef OEI_SDP_TIMING
+#define SDP_TIC(var) const long long var = clock64()
+#define SDP_TOC(slot, var) do { if (threadIdx.x == 0) w.scal[slot] += (double)(clock64() - (var)); } while (0)
+#else
+#define SDP_TIC(var)
+#define SDP_TOC(slot, var)
+#endif
+
 struct SdpWork {
     int q, LD;
     double *S, *X, *V, *R, *H, *Kt;                                // q x LD matrices
@@ -50,12 +60,21 @@ __host__ __device__ inline size_t sdp_work_doubles(int q) {
     return (size_t)6 * q * LD + (size_t)11 * VL + 3 * VL + VL /* ri,rj as ints */ + 8;
 }
 
+// Callers may use the block starting at w.X (X, V, R, Kt and whatever follows) as a staging buffer
+// of `stage` doubles while no solver state is live.  Size of the region that must be reserved:
+__host__ __device__ inline size_t sdp_region_doubles(int q, size_t stage) {
+    const size_t work = sdp_work_doubles(q), alt = (size_t)2 * q * sdp_ld(q) + stage;
+    return work > alt ? work : alt;
+}
+
 __device__ inline void sdp_carve(SdpWork& w, double* base, int q) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
     w.q = q; w.LD = LD;
     double* ptr = base;
-    w.S = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;  w.V = ptr; ptr += q * LD;
-    w.R = ptr; ptr += q * LD;  w.H = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD;
+    // S and H first: X, V, R, Kt are contiguous so callers can stage through them while the
+    // solver is idle (sdp_stage_offset)
+    w.S = ptr; ptr += q * LD;  w.H = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;
+    w.V = ptr; ptr += q * LD;  w.R = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD;
     w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
     w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
     w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;
@@ -152,8 +171,9 @@ __device__ int sdp_jacobi(const SdpWork& w) {
 
 // ---- evaluate g, grad g and the eigen-state at the point pt (length q, in LDS) ------------------
 // Returns g, or -inf when pt leaves the simplex or X loses positive definiteness numerically.
+// LDS variant (any workgroup size): two-sided Jacobi on X = W S W^T; needs w.S = S.
 template <int T>
-__device__ double sdp_eval(const SdpWork& w, const double* pt, int& sweeps) {
+__device__ double sdp_eval_lds(const SdpWork& w, const double* pt, int& sweeps) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     double sum = 0.0, pmin = INFINITY;
@@ -216,14 +236,210 @@ __device__ double sdp_eval(const SdpWork& w, const double* pt, int& sweeps) {
     return g;
 }
 
+
+// ---- one-sided Jacobi in registers: lane j owns column j of G (X = G^T G) and of V --------------
+// Pairs of a round exchange columns with wave shuffles; a rotation needs alpha = |g_i|^2,
+// beta = |g_j|^2, gamma = g_i . g_j only.  Q is the padded size (even); columns >= q are zero and
+// never rotate.  Returns the number of sweeps.  Singular values end up as column norms.
+template <int Q>
+__device__ int sdp_jacobi_reg(double (&g)[Q], double (&v)[Q]) {
+    const int lane = threadIdx.x & 63;
+    int sweep = 0;
+    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
+        bool rotated = false;
+        for (int r = 0; r < Q - 1; ++r) {
+            int partner = lane;
+            if (lane < Q - 1) {
+                partner = (2 * r - lane) % (Q - 1);
+                if (partner < 0) partner += Q - 1;
+                if (partner == lane) partner = Q - 1;
+            } else if (lane == Q - 1) {
+                partner = r;
+            }
+            double pg[Q];
+            double alpha = 0.0, gamma = 0.0;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) pg[k] = __shfl(g[k], partner, 64);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) { alpha += g[k] * g[k]; gamma += g[k] * pg[k]; }
+            const double beta = __shfl(alpha, partner, 64);
+            const bool low = lane < partner;
+            const double ai = low ? alpha : beta, aj = low ? beta : alpha;
+            double c = 1.0, sg = 0.0;
+            const bool rot = (lane < Q) && (partner != lane) &&
+                             (gamma * gamma > SDP_JACOBI_TOL * SDP_JACOBI_TOL * ai * aj);
+            if (rot) {
+                const double zeta = (aj - ai) / (2.0 * gamma);
+                double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                if (zeta < 0.0) t = -t;
+                c = 1.0 / sqrt(1.0 + t * t);
+                sg = low ? -t * c : t * c;       // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
+            }
+            rotated |= rot;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) g[k] = c * g[k] + sg * pg[k];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                const double pv = __shfl(v[k], partner, 64);
+                v[k] = c * v[k] + sg * pv;
+            }
+        }
+        if (!__any(rotated)) { ++sweep; break; }
+    }
+    return sweep;
+}
+
+// In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed).  The register
+// variant of the evaluation works on G = Lc^T W^T instead of X.  Returns non-zero if S is not PD.
+template <int T>
+__device__ int sdp_factor(const SdpWork& w) {
+    if (T != 64) return 0;              // the LDS variant keeps S itself
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    __syncthreads();
+    for (int k = 0; k < q; ++k) {
+        const double akk = w.S[k * LD + k];
+        if (!(akk > 0.0)) return 1;     // identical in every thread
+        const double piv = sqrt(akk);
+        __syncthreads();
+        if (tid == 0) w.S[k * LD + k] = piv;
+        for (int i = k + 1 + tid; i < q; i += T) w.S[i * LD + k] /= piv;
+        __syncthreads();
+        const int rem = q - k - 1;
+        for (int e = tid; e < rem * rem; e += T) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j <= i) w.S[i * LD + j] -= w.S[i * LD + k] * w.S[j * LD + k];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, j = e - i * q;
+        if (j > i) w.S[i * LD + j] = 0.0;
+    }
+    __syncthreads();
+    return 0;
+}
+
+// Register variant (one 64-lane wave, q <= Q <= 32): needs w.S = Lc (sdp_factor).  With `warm`
+// the previous eigenvectors in w.V seed the iteration (G <- G V), which saves sweeps once the
+// Newton steps get short.
+template <int Q>
+__device__ double sdp_eval_reg(const SdpWork& w, const double* pt, int& sweeps, bool warm) {
+    constexpr int T = 64;
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    SDP_TIC(t_setup);
+    double sum = 0.0, pmin = INFINITY;
+    for (int i = 0; i < q; ++i) { sum += pt[i]; pmin = fmin(pmin, pt[i]); }
+    const double p0 = 1.0 - sum;
+    if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
+    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), gamp = gam / sp0;
+    __syncthreads();
+    if (tid < q) {
+        w.s[tid] = sqrt(pt[tid]);
+        double acc = 0.0;                       // m = Lc^T p
+        for (int i = tid; i < q; ++i) acc += w.S[i * LD + tid] * pt[i];
+        w.tv[tid] = acc;
+    }
+    __syncthreads();
+    double g[Q], v[Q];
+    {   // column j of G = s_j (Lc^T e_j - gam m)
+        const double sj = (tid < q) ? w.s[tid] : 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k)
+            g[k] = (tid < q && k < q) ? sj * (w.S[tid * LD + k] - gam * w.tv[k]) : 0.0;
+    }
+    if (warm) {
+        if (tid < q) {
+#pragma unroll
+            for (int k = 0; k < Q; ++k) if (k < q) w.X[k * LD + tid] = g[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < Q; ++k) { g[k] = 0.0; v[k] = (tid < q && k < q) ? w.V[k * LD + tid] : 0.0; }
+        if (tid < q) {
+            for (int j = 0; j < q; ++j) {
+                const double vj = w.V[j * LD + tid];
+#pragma unroll
+                for (int k = 0; k < Q; ++k) if (k < q) g[k] += w.X[k * LD + j] * vj;
+            }
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) v[k] = (k == tid) ? 1.0 : 0.0;
+    }
+    SDP_TOC(0, t_setup);
+    SDP_TIC(t_jac);
+    sweeps += sdp_jacobi_reg<Q>(g, v);
+    SDP_TOC(1, t_jac);
+    SDP_TIC(t_rest);
+    int bad = 0;
+    if (tid < q) {
+        double nrm = 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) nrm += g[k] * g[k];
+        if (!(nrm > 0.0)) bad = 1;
+        w.sq[tid] = sqrt(fmax(nrm, 1e-300));
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if (k < q) w.V[k * LD + tid] = v[k];
+    }
+    __syncthreads();
+    if (tid < q) {
+        double acc = 0.0;
+        for (int k = 0; k < q; ++k) acc += w.s[k] * w.V[k * LD + tid];
+        w.sv[tid] = acc;
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) return -INFINITY;
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        w.R[i * LD + a] = w.V[i * LD + a] / w.s[i] + gamp * w.sv[a];
+    }
+    __syncthreads();
+    if (tid < q) {
+        double acc = 0.0;
+        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * pt[i];
+        w.rp[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < q) {
+        double db = 0.0, bp = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
+            db += r * rs;
+            bp += rs * w.rp[a];
+        }
+        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
+    }
+    __syncthreads();
+    double gval = 0.0;
+    for (int a = 0; a < q; ++a) gval += w.sq[a] - pt[a] * w.dl[a];
+    SDP_TOC(2, t_rest);
+    return gval;
+}
+
+
+template <int T>
+__device__ double sdp_eval(const SdpWork& w, const double* pt, int& sweeps, bool warm) {
+    if constexpr (T == 64) {
+        if (w.q <= 8) return sdp_eval_reg<8>(w, pt, sweeps, warm);
+        if (w.q <= 16) return sdp_eval_reg<16>(w, pt, sweeps, warm);
+        if (w.q <= 20) return sdp_eval_reg<20>(w, pt, sweeps, warm);
+        return sdp_eval_reg<32>(w, pt, sweeps, warm);
+    } else {
+        return sdp_eval_lds<T>(w, pt, sweeps);
+    }
+}
+
 // ---- Newton direction at the state left by sdp_eval(w.p): w.step = (-hess g)^-1 grad g ----------
 // Returns 0 on success, 1 if -hess g is not numerically positive definite.
 template <int T>
 __device__ int sdp_newton_dir(const SdpWork& w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    double* Wv = w.X;      // eigen-decomposition finished: X and V are free for reuse
-    double* Bh = w.V;      // B/2 = R sq R^T
+    double* Wv = w.X;      // eigen-decomposition finished: X is free for reuse (V is kept: it
+                           // seeds the next eigendecomposition)
     __syncthreads();
     for (int e = tid; e < q * q; e += T) {
         const int i = e / q, a = e - i * q;
@@ -248,19 +464,10 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         w.ci[i] = acc;
         w.tv[i] = acc0 * mi * mi;
     }
-    // B/2
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, j = e - i * q;
-        if (j > i) continue;
-        double acc = 0.0;
-        for (int a = 0; a < q; ++a) acc += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
-        Bh[i * LD + j] = acc;
-        Bh[j * LD + i] = acc;
-    }
     __syncthreads();
     double c0 = 0.0;
     for (int i = 0; i < q; ++i) c0 += w.tv[i];
-    // A = -hess = 1/2 (Q - ci - cj + c0) + B/2, lower triangle
+    // A = -hess = 1/2 (Q - ci - cj + c0) + B/2, lower triangle;  B/2 = R sq R^T
     const int npair = q * (q + 1) / 2;
     for (int e = tid; e < npair; e += T) {
         // unrank e -> (i >= j)
@@ -268,16 +475,16 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
         const int j = e - i * (i + 1) / 2;
-        double Q = 0.0;
+        double Q = 0.0, bh = 0.0;
         for (int a = 0; a < q; ++a) {
             const double za = Wv[i * LD + a] * Wv[j * LD + a];
             double inner = 0.5 * w.Kt[a * LD + a] * za;
             for (int b = 0; b < a; ++b) inner += w.Kt[a * LD + b] * (Wv[i * LD + b] * Wv[j * LD + b]);
             Q += za * inner;
+            bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
         }
         Q *= 2.0;
-        const double val = 0.5 * (Q - w.ci[i] - w.ci[j] + c0) + Bh[i * LD + j];
-        w.H[i * LD + j] = val;
+        w.H[i * LD + j] = 0.5 * (Q - w.ci[i] - w.ci[j] + c0) + bh;
     }
     __syncthreads();
     // in-place Cholesky of A (lower) and solve A step = grad
@@ -336,10 +543,17 @@ __device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
     if (tid < q) w.p[tid] = fmax(w.pn[tid] / (1.0 + tot), 1e-300);
     __syncthreads();
     int sweeps = 0, it = 0, status = 1;
-    double g = sdp_eval<T>(w, w.p, sweeps);
+#ifdef OEI_SDP_TIMING
+    if (tid == 0) { w.scal[0] = w.scal[1] = w.scal[2] = w.scal[3] = 0.0; }
+#endif
+    if (sdp_factor<T>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
+    double g = sdp_eval<T>(w, w.p, sweeps, false);
     if (!(g > -INFINITY)) { *g_out = g; *iters_out = 0; return 2; }
     for (it = 1; it <= SDP_MAX_NEWTON; ++it) {
-        if (sdp_newton_dir<T>(w)) { status = 2; break; }
+        SDP_TIC(t_dir);
+        const int dir_fail = sdp_newton_dir<T>(w);
+        SDP_TOC(3, t_dir);
+        if (dir_fail) { status = 2; break; }
         double rel = 0.0, ssum = 0.0, dec = 0.0, psum = 0.0;
         for (int i = 0; i < q; ++i) {
             const double st = w.step[i];
@@ -357,7 +571,7 @@ __device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
             __syncthreads();
             if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
             __syncthreads();
-            gn = sdp_eval<T>(w, w.pn, sweeps);
+            gn = sdp_eval<T>(w, w.pn, sweeps, true);
             if (gn >= g + 1e-4 * t * dec - slack) break;
             t *= 0.5; full = false;
         }

@@ -75,6 +75,10 @@ __global__ __launch_bounds__(T) void k_sdp_omega(int q, const double* __restrict
         }
     }
     if (tid == 0) { value[b] = -w0 * g; status[b] = st; if (iters) iters[b] = it; }
+#ifdef OEI_SDP_TIMING
+    __syncthreads();
+    if (tid < 4) M[(size_t)b * k_ * k_ + tid] = w.scal[tid];     // diagnostic build: phase cycles
+#endif
 }
 
 extern "C" int oei_sdp_batched(int B, int k_, const double* omega, const double* fmin,

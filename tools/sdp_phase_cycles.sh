@@ -1,0 +1,11 @@
+#!/bin/bash
+# Diagnostic: builds a timing variant of the library (not the shipped one) and prints the cycles
+# the SDP solver spends per phase for one wave.  Run from the repo root on a GPU box.
+set -e
+D=$(mktemp -d)
+for f in oei_model oei_gemm oei_sdp oei_acq oei_hess; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DOEI_SDP_TIMING -c bayesian_optimization_amd/csrc/$f.hip -o $D/$f.o 2>/dev/null &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboei_timing.so $D/*.o
+OEI_LIB_OVERRIDE=$D/liboei_timing.so python tools/sdp_phase_cycles.py "$@"
