@@ -18,8 +18,8 @@
 template <int T>
 __device__ void posterior_moments(const SdpWork& w, const KernParams& kp, double noise, int n,
                                   int npad, size_t astride, const double* __restrict__ Arows,
-                                  const double* __restrict__ v, const double* xq, double* mu,
-                                  double* Ac, double* vc) {
+                                  const double* __restrict__ v, const lds_f64* xq, lds_f64* mu,
+                                  lds_f64* Ac, lds_f64* vc) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD, d = kp.d;
     const int npair = q * (q + 1) / 2, nitems = npair + q;
@@ -52,8 +52,8 @@ __device__ void posterior_moments(const SdpWork& w, const KernParams& kp, double
 #pragma unroll
         for (int u = 0; u < ITEMS_MAX; ++u) {
             if (u * T >= nitems) break;                  // uniform; idle lanes redo item 0
-            const double* ra = Ac + ii[u] * (CH + 1);
-            const double* rb = (jj[u] >= 0) ? Ac + jj[u] * (CH + 1) : vc;
+            const lds_f64* ra = Ac + ii[u] * (CH + 1);
+            const lds_f64* rb = (jj[u] >= 0) ? Ac + jj[u] * (CH + 1) : vc;
             double s = 0.0;
 #pragma unroll 4
             for (int k = 0; k < CH; ++k) s += ra[k] * rb[k];
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q);
-    double* mu = sm + sdp_region_doubles(q, acq_stage_doubles(q));
-    double* xq = mu + q + 2;
-    double* Ac = w.X;
-    double* vc = Ac + q * (CH + 1);
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q));
+    lds_f64* xq = mu + q + 2;
+    lds_f64* Ac = w.X;
+    lds_f64* vc = Ac + q * (CH + 1);
     const int tid = threadIdx.x, b = blockIdx.x, k_ = q + 1, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
@@ -133,10 +133,10 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q);
-    double* mu = sm + sdp_region_doubles(q, acq_stage_doubles(q));
-    double* xq = mu + q + 2;
-    double* Ac = w.X;
-    double* vc = Ac + q * (CH + 1);
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q));
+    lds_f64* xq = mu + q + 2;
+    lds_f64* Ac = w.X;
+    lds_f64* vc = Ac + q * (CH + 1);
     const int tid = threadIdx.x, b = blockIdx.x, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();

@@ -27,10 +27,10 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
     SdpWork w;
     sdp_carve(w, sm, q);
     const int VL = sdp_vlen(q), LD = w.LD, k_ = q + 1;
-    double* mu = sm + sdp_work_doubles(q);
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q);
     SensVec sv;
     sens_carve(sv, mu + VL, q);
-    double* Sc = mu + VL + SENS_NVEC * VL;            // copy of S (+ mu mu^T) for dw0 != 0
+    lds_f64* Sc = mu + VL + SENS_NVEC * VL;            // copy of S (+ mu mu^T) for dw0 != 0
     const int tid = threadIdx.x, b = blockIdx.x;
     const double* Yb = Yin + (size_t)b * k_ * k_ * k_;
     // Omega = sum_i Y_i
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
         if (dY && K == 1) {
             // y_blk = sqrt(w0 p_blk) [x_blk; 1], x_0 = c, x_i = c - (B/2) e_i;  dY = y dy^T + dy y^T
             __syncthreads();
-            double* Bh = w.V;       // B/2  = Rs R^T
-            double* dBh = Sc;       // dB/2 = -2 Rs Z Rs^T
+            lds_f64* Bh = w.V;       // B/2  = Rs R^T
+            lds_f64* dBh = Sc;       // dB/2 = -2 Rs Z Rs^T
             for (int e = tid; e < q * q; e += T) {
                 const int i = e / q, l = e - i * q;
                 double bh = 0.0, db = 0.0;
@@ -174,9 +174,9 @@ __device__ __forceinline__ double gsym(const double* __restrict__ Gb, int RP, in
 // mu[a], DS[a][l][b] = d Sigma_ab / d x_al (b == a: the full derivative of Sigma_aa),
 // dmuT[a][l] = d mu_a / d x_al, k1s[a][b] = 2 var kappa'(t_ab), k2s[a][b] = 4 var kappa''(t_ab).
 template <int T>
-__device__ void build_tables(const KernParams& kp, int q, const double* xq,
-                             const double* __restrict__ Gb, int RP, double* mu, double* DS,
-                             double* dmuT, double* k1s, double* k2s) {
+__device__ void build_tables(const KernParams& kp, int q, const lds_f64* xq,
+                             const double* __restrict__ Gb, int RP, lds_f64* mu, lds_f64* DS,
+                             lds_f64* dmuT, lds_f64* k1s, lds_f64* k2s) {
     const int tid = threadIdx.x, d = kp.d, dp = d + 1, vrow = q * dp;
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, b = e - a * q;
@@ -213,12 +213,12 @@ __global__ __launch_bounds__(T) void k_domega(KernParams kp, int q, int RP,
                                               double* __restrict__ domega) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int d = kp.d, qd = q * d, k_ = q + 1;
-    double* xq = sm;                    // [q*d]
-    double* mu = xq + qd;               // [q]
-    double* DS = mu + q;                // [q*d*q]
-    double* dmuT = DS + qd * q;         // [q*d]
-    double* k1s = dmuT + qd;            // [q*q]
-    double* k2s = k1s + q * q;          // [q*q]
+    lds_f64* xq = (lds_f64*)sm;          // [q*d]
+    lds_f64* mu = xq + qd;               // [q]
+    lds_f64* DS = mu + q;                // [q*d*q]
+    lds_f64* dmuT = DS + qd * q;         // [q*d]
+    lds_f64* k1s = dmuT + qd;            // [q*q]
+    lds_f64* k2s = k1s + q * q;          // [q*q]
     const int tid = threadIdx.x;
     const size_t b = blockIdx.x;
     for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
@@ -278,17 +278,17 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
     SdpWork w;
     sdp_carve(w, sm, q);
     const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d, dl = (d + 1) | 1;
-    double* mu = sm + sdp_work_doubles(q);
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q);
     SensVec sv;
     sens_carve(sv, mu + VL, q);
-    double* dNmu = mu + VL + SENS_NVEC * VL;    // [VL]
-    double* xq = dNmu + VL;                     // [q*d]
-    double* tab = xq + qd;                      // DS [q*d*q], first used as chunk staging
-    double* dmuT = tab + hess_tab_doubles(q, d);
-    double* k1s = dmuT + qd;
-    double* k2s = k1s + q * q;
-    double* M11 = k2s + q * q;
-    double* Dg = M11 + q * q;                   // [q][d][d]
+    lds_f64* dNmu = mu + VL + SENS_NVEC * VL;    // [VL]
+    lds_f64* xq = dNmu + VL;                     // [q*d]
+    lds_f64* tab = xq + qd;                      // DS [q*d*q], first used as chunk staging
+    lds_f64* dmuT = tab + hess_tab_doubles(q, d);
+    lds_f64* k1s = dmuT + qd;
+    lds_f64* k2s = k1s + q * q;
+    lds_f64* M11 = k2s + q * q;
+    lds_f64* Dg = M11 + q * q;                   // [q][d][d]
     const int tid = threadIdx.x;
     const size_t b = blockIdx.x;
     const double* Gb = G + b * (size_t)RP * RP;
@@ -304,9 +304,9 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
         int ch = (int)((tabsz - 2 * q) / (2 * q + dl));
         ch = (ch / 16) * 16;
         if (ch > 64) ch = 64;
-        double* c1 = tab;                        // [q][ch+1]  coef * 2 var kappa'
-        double* c2 = c1 + q * (ch + 1);          // [q][ch+1]  coef * 4 var kappa''
-        double* Xc = c2 + q * (ch + 1);          // [ch][dl]
+        lds_f64* c1 = tab;                        // [q][ch+1]  coef * 2 var kappa'
+        lds_f64* c2 = c1 + q * (ch + 1);          // [q][ch+1]  coef * 4 var kappa''
+        lds_f64* Xc = c2 + q * (ch + 1);          // [ch][dl]
         const int nsym = d * (d + 1) / 2;
         const int nitems = q * nsym;             // per a: one item per (l <= m)
         for (int e = tid; e < q * d * d; e += T) Dg[e] = 0.0;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
 
     // ---- tables, moments, state at the optimum --------------------------------------------------
     build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
-    double* DS = tab;
+    lds_f64* DS = tab;
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, c = e - a * q;
         double t = 0.0;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
             const int bb = bm / d, m2 = bm - bb * d;
             // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
             double acc = 0.0;
-            const double* dsrow = DS + (size_t)bm * q;
+            const lds_f64* dsrow = DS + (size_t)bm * q;
             for (int c = 0; c < q; ++c) acc += w.X[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
             double P = -acc + 2.0 * dmuT[bm] * (sv.w1[bb] + sv.w2[bb] - dNmu[bb]);
             // d2<Omega,M>/dx2 at fixed M

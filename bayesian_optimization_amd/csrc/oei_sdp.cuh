@@ -10,12 +10,12 @@
 //   g(p) = tr (S^1/2 D(p) S^1/2)^1/2 - p^T delta,     D(p) = diag(p) - p p^T,     value = -w0 max g,
 //
 // where p_i is the weight of the i-th rank-one dual block Y_i (p_0 = 1 - sum p that of Y_0).
-// g is maximised by a damped Newton iteration.  Every evaluation needs one symmetric
-// eigendecomposition of the q x q matrix X = W S W^T (D = W^T W), done with a cyclic two-sided
-// Jacobi iteration whose rotations are applied as independent 2x2 blocks, all in LDS:
+// g is maximised by a damped Newton iteration.  Every evaluation needs the singular values and
+// right singular vectors of a q x q matrix G with G^T G = X = W S W^T (D = W^T W):
 //
-//   W = (I - gamma s s^T) diag(s),  s = sqrt(p),  gamma = 1/(1 + sqrt(p0))
-//   X = V diag(lam) V^T,  sq = sqrt(lam),  R = W^-1 V,  U = W^T V
+//   W = diag(s) (I - gamma 1 p^T),  s = sqrt(p),  gamma = 1/(1 + sqrt(p0)),  S = Lc Lc^T
+//   G = Lc^T W^T,  G V = (orthogonal columns of norms sq),  U = W^T V = Lc^-T (G V),
+//   R = W^-1 V = D^-1 U = U / p + 1 (1^T U) / p0
 //   B = 2 R diag(sq) R^T,   N = B^-1 = 1/2 U diag(1/sq) U^T
 //   grad g = diag(B)/4 - B p/2 - delta
 //   hess g = -1/2 sum_ab K_ab E_i,ab E_j,ab - B/2,   K_ab = 1/(sq_a sq_b (sq_a + sq_b)),
@@ -23,6 +23,13 @@
 //   M = -[[N, -N c], [-(N c)^T, c^T N c]],  c = mu + B p / 2
 //   y_0 = sqrt(w0 p0) [c; 1],  y_i = sqrt(w0 p_i) [c - B e_i / 2; 1],  Y_i = y_i y_i^T
 //
+// Two implementations of the decomposition:
+//   * q <= 32, one 64-lane wave: one-sided (Hestenes) Jacobi with lane j holding column j of G in
+//     registers; the pairs of a round exchange columns with wave shuffles, no LDS traffic and no
+//     eigenvector accumulation (U follows from a triangular solve with Lc).  The previous U seeds
+//     the next evaluation (G <- G V_prev), which saves sweeps as the Newton steps shrink.
+//   * larger q, 256 threads: two-sided Jacobi on X in LDS, rotations applied as independent 2x2
+//     blocks.
 // All matrices are q x q with an odd leading dimension LD so that row and column walks are free
 // of LDS bank conflicts.  Every thread of the workgroup executes every call (barriers inside).
 #pragma once
@@ -32,9 +39,16 @@
 #define SDP_MAX_SWEEPS 30
 #define SDP_JACOBI_TOL 1e-15
 #define SDP_STEP_TOL 1e-7
+#define SDP_JACOBI_FINAL 1e-7
+
+// Pointers into LDS carry their address space in the type: pointers that pass through a struct
+// would otherwise degrade to generic (flat) accesses, which are several times slower than ds_*.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
 
 // Diagnostic build only (-DOEI_SDP_TIMING): cycle counters per solver phase in w.scal[0..3]
-// (set-up of an evaluation, Jacobi, rest of the evaluation, Newton direction).
+// (0 set-up of an evaluation, 1 Jacobi, 2 rest of the evaluation, 3 Newton direction, of which
+// 4 Hessian assembly, 5 Cholesky, 6 triangular solves).
 #ifdef OEI_SDP_TIMING
 #define SDP_TIC(var) const long long var = clock64()
 #define SDP_TOC(slot, var) do { if (threadIdx.x == 0) w.scal[slot] += (double)(clock64() - (var)); } while (0)
@@ -45,11 +59,11 @@
 
 struct SdpWork {
     int q, LD;
-    double *S, *X, *V, *R, *H, *Kt;                                // q x LD matrices
-    double *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci;  // vectors (length q)
-    double *rc, *rs, *rt;                                          // rotation parameters
-    int *ri, *rj;
-    double *scal;                                                  // [8] scalars
+    lds_f64 *S, *X, *V, *R, *H, *Kt;                                // q x LD matrices
+    lds_f64 *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci;  // vectors (length q)
+    lds_f64 *rc, *rs, *rt;                                          // rotation parameters / scratch
+    lds_i32 *ri, *rj;
+    lds_f64 *scal;                                                  // [8] scalars
 };
 
 __host__ __device__ inline int sdp_ld(int q) { return q | 1; }
@@ -70,20 +84,22 @@ __host__ __device__ inline size_t sdp_region_doubles(int q, size_t stage) {
 __device__ inline void sdp_carve(SdpWork& w, double* base, int q) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
     w.q = q; w.LD = LD;
-    double* ptr = base;
+    lds_f64* ptr = (lds_f64*)base;
     // S and H first: X, V, R, Kt are contiguous so callers can stage through them while the
-    // solver is idle (sdp_stage_offset)
+    // solver is idle (sdp_region_doubles)
     w.S = ptr; ptr += q * LD;  w.H = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;
     w.V = ptr; ptr += q * LD;  w.R = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD;
     w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
     w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
     w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;
     w.rc = ptr; ptr += VL; w.rs = ptr; ptr += VL;  w.rt = ptr; ptr += VL;
-    w.ri = reinterpret_cast<int*>(ptr); w.rj = w.ri + VL; ptr += VL;
+    w.ri = (lds_i32*)ptr; w.rj = w.ri + VL; ptr += VL;
     w.scal = ptr;
 }
 
-// ---- cyclic Jacobi on w.X (symmetric, full storage); eigenvectors accumulate in w.V ------------
+// ================================================================================================
+// LDS variant (any workgroup size): two-sided cyclic Jacobi on w.X, eigenvectors in w.V
+// ================================================================================================
 // Round-robin ordering: in round r, slot 0 pairs (qe-1, r) and slot k pairs ((r+k), (r-k)) mod
 // (qe-1); qe = q rounded up to even, pairs touching the padding index are idle.  For one round the
 // np x np grid of 2x2 blocks X[{i_k,j_k},{i_l,j_l}] <- J_k^T (.) J_l is updated independently.
@@ -92,8 +108,8 @@ __device__ int sdp_jacobi(const SdpWork& w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const int qe = q + (q & 1), np = qe >> 1, nm1 = qe - 1;
-    double* X = w.X;
-    double* V = w.V;
+    lds_f64* X = w.X;
+    lds_f64* V = w.V;
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
         int rotated = 0;
@@ -169,18 +185,52 @@ __device__ int sdp_jacobi(const SdpWork& w) {
     return sweep;
 }
 
+// Shared tail of both evaluation variants.  In: w.X = U, w.sv = column sums of U, w.sq, pt.
+// Out: w.R, w.rp, w.grad; returns g.
+template <int T>
+__device__ double sdp_eval_tail(const SdpWork& w, const lds_f64* pt, double p0) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const double ip0 = 1.0 / p0;
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        w.R[i * LD + a] = w.X[i * LD + a] / pt[i] + w.sv[a] * ip0;
+    }
+    __syncthreads();
+    if (tid < q) {
+        double acc = 0.0;
+        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * pt[i];
+        w.rp[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < q) {
+        double db = 0.0, bp = 0.0;
+#pragma unroll 4
+        for (int a = 0; a < q; ++a) {
+            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
+            db += r * rs;
+            bp += rs * w.rp[a];
+        }
+        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
+    }
+    __syncthreads();
+    double g = 0.0;
+    for (int a = 0; a < q; ++a) g += w.sq[a] - pt[a] * w.dl[a];
+    return g;
+}
+
 // ---- evaluate g, grad g and the eigen-state at the point pt (length q, in LDS) ------------------
 // Returns g, or -inf when pt leaves the simplex or X loses positive definiteness numerically.
-// LDS variant (any workgroup size): two-sided Jacobi on X = W S W^T; needs w.S = S.
+// LDS variant: needs w.S = S.  Leaves U in w.X.
 template <int T>
-__device__ double sdp_eval_lds(const SdpWork& w, const double* pt, int& sweeps) {
+__device__ double sdp_eval_lds(const SdpWork& w, const lds_f64* pt, int& sweeps) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     double sum = 0.0, pmin = INFINITY;
     for (int i = 0; i < q; ++i) { sum += pt[i]; pmin = fmin(pmin, pt[i]); }
     const double p0 = 1.0 - sum;
     if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
-    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), gamp = gam / sp0;
+    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0);
     __syncthreads();           // previous readers of s/tv/X/V are done
     if (tid < q) {
         w.s[tid] = sqrt(pt[tid]);
@@ -204,45 +254,34 @@ __device__ double sdp_eval_lds(const SdpWork& w, const double* pt, int& sweeps) 
         const double lam = w.X[tid * LD + tid];
         if (!(lam > 0.0)) bad = 1;
         w.sq[tid] = sqrt(fmax(lam, 1e-300));
-        double acc = 0.0;
+        double acc = 0.0;                  // (s^T V)_a
         for (int k = 0; k < q; ++k) acc += w.s[k] * w.V[k * LD + tid];
-        w.sv[tid] = acc;
+        w.tv[tid] = acc;
     }
     bad = __syncthreads_or(bad);
     if (bad) return -INFINITY;
-    for (int e = tid; e < q * q; e += T) {
+    for (int e = tid; e < q * q; e += T) {        // U = W^T V
         const int i = e / q, a = e - i * q;
-        w.R[i * LD + a] = w.V[i * LD + a] / w.s[i] + gamp * w.sv[a];
+        w.X[i * LD + a] = w.s[i] * w.V[i * LD + a] - gam * pt[i] * w.tv[a];
     }
     __syncthreads();
     if (tid < q) {
         double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * pt[i];
-        w.rp[tid] = acc;
+        for (int i = 0; i < q; ++i) acc += w.X[i * LD + tid];
+        w.sv[tid] = acc;
     }
     __syncthreads();
-    if (tid < q) {
-        double db = 0.0, bp = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
-            db += r * rs;
-            bp += rs * w.rp[a];
-        }
-        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
-    }
-    __syncthreads();
-    double g = 0.0;
-    for (int a = 0; a < q; ++a) g += w.sq[a] - pt[a] * w.dl[a];
-    return g;
+    return sdp_eval_tail<T>(w, pt, p0);
 }
 
-
-// ---- one-sided Jacobi in registers: lane j owns column j of G (X = G^T G) and of V --------------
-// Pairs of a round exchange columns with wave shuffles; a rotation needs alpha = |g_i|^2,
-// beta = |g_j|^2, gamma = g_i . g_j only.  Q is the padded size (even); columns >= q are zero and
-// never rotate.  Returns the number of sweeps.  Singular values end up as column norms.
+// ================================================================================================
+// Register variant (one 64-lane wave, q <= Q <= 32)
+// ================================================================================================
+// One-sided Jacobi: lane j owns column j of G.  Pairs of a round exchange columns with wave
+// shuffles; a rotation needs alpha = |g_i|^2, beta = |g_j|^2, gamma = g_i . g_j only.  Q is the
+// padded size (even); columns >= q are zero and never rotate.  Returns the number of sweeps.
 template <int Q>
-__device__ int sdp_jacobi_reg(double (&g)[Q], double (&v)[Q]) {
+__device__ int sdp_jacobi_reg(double (&g)[Q]) {
     const int lane = threadIdx.x & 63;
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
@@ -266,8 +305,9 @@ __device__ int sdp_jacobi_reg(double (&g)[Q], double (&v)[Q]) {
             const bool low = lane < partner;
             const double ai = low ? alpha : beta, aj = low ? beta : alpha;
             double c = 1.0, sg = 0.0;
+            const double g2 = gamma * gamma, aa = ai * aj;
             const bool rot = (lane < Q) && (partner != lane) &&
-                             (gamma * gamma > SDP_JACOBI_TOL * SDP_JACOBI_TOL * ai * aj);
+                             (g2 > SDP_JACOBI_TOL * SDP_JACOBI_TOL * aa);
             if (rot) {
                 const double zeta = (aj - ai) / (2.0 * gamma);
                 double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -275,22 +315,19 @@ __device__ int sdp_jacobi_reg(double (&g)[Q], double (&v)[Q]) {
                 c = 1.0 / sqrt(1.0 + t * t);
                 sg = low ? -t * c : t * c;       // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
             }
-            rotated |= rot;
+            // the iteration converges quadratically: once every rotation of a sweep had
+            // |gamma| <= 1e-7 sqrt(alpha beta), what is left afterwards is below the tolerance
+            rotated |= rot && (g2 > SDP_JACOBI_FINAL * SDP_JACOBI_FINAL * aa);
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = c * g[k] + sg * pg[k];
-#pragma unroll
-            for (int k = 0; k < Q; ++k) {
-                const double pv = __shfl(v[k], partner, 64);
-                v[k] = c * v[k] + sg * pv;
-            }
         }
         if (!__any(rotated)) { ++sweep; break; }
     }
     return sweep;
 }
 
-// In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed).  The register
-// variant of the evaluation works on G = Lc^T W^T instead of X.  Returns non-zero if S is not PD.
+// In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed), reciprocal
+// diagonal in w.rc.  Only the register variant needs it.  Returns non-zero if S is not PD.
 template <int T>
 __device__ int sdp_factor(const SdpWork& w) {
     if (T != 64) return 0;              // the LDS variant keeps S itself
@@ -302,7 +339,7 @@ __device__ int sdp_factor(const SdpWork& w) {
         if (!(akk > 0.0)) return 1;     // identical in every thread
         const double piv = sqrt(akk);
         __syncthreads();
-        if (tid == 0) w.S[k * LD + k] = piv;
+        if (tid == 0) { w.S[k * LD + k] = piv; w.rc[k] = 1.0 / piv; }
         for (int i = k + 1 + tid; i < q; i += T) w.S[i * LD + k] /= piv;
         __syncthreads();
         const int rem = q - k - 1;
@@ -320,11 +357,11 @@ __device__ int sdp_factor(const SdpWork& w) {
     return 0;
 }
 
-// Register variant (one 64-lane wave, q <= Q <= 32): needs w.S = Lc (sdp_factor).  With `warm`
-// the previous eigenvectors in w.V seed the iteration (G <- G V), which saves sweeps once the
-// Newton steps get short.
+// Needs w.S = Lc, w.rc = 1/diag(Lc) (sdp_factor).  With `warm`, w.V holds the right singular
+// vectors of the previous evaluation and seeds this one (G <- G V).  Leaves U in w.X and the new
+// V in w.V.
 template <int Q>
-__device__ double sdp_eval_reg(const SdpWork& w, const double* pt, int& sweeps, bool warm) {
+__device__ double sdp_eval_reg(const SdpWork& w, const lds_f64* pt, int& sweeps, bool warm) {
     constexpr int T = 64;
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
@@ -342,7 +379,7 @@ __device__ double sdp_eval_reg(const SdpWork& w, const double* pt, int& sweeps, 
         w.tv[tid] = acc;
     }
     __syncthreads();
-    double g[Q], v[Q];
+    double g[Q];
     {   // column j of G = s_j (Lc^T e_j - gam m)
         const double sj = (tid < q) ? w.s[tid] : 0.0;
 #pragma unroll
@@ -356,8 +393,9 @@ __device__ double sdp_eval_reg(const SdpWork& w, const double* pt, int& sweeps, 
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < Q; ++k) { g[k] = 0.0; v[k] = (tid < q && k < q) ? w.V[k * LD + tid] : 0.0; }
+        for (int k = 0; k < Q; ++k) g[k] = 0.0;
         if (tid < q) {
+#pragma unroll 2
             for (int j = 0; j < q; ++j) {
                 const double vj = w.V[j * LD + tid];
 #pragma unroll
@@ -365,63 +403,55 @@ __device__ double sdp_eval_reg(const SdpWork& w, const double* pt, int& sweeps, 
             }
         }
         __syncthreads();
-    } else {
-#pragma unroll
-        for (int k = 0; k < Q; ++k) v[k] = (k == tid) ? 1.0 : 0.0;
     }
     SDP_TOC(0, t_setup);
     SDP_TIC(t_jac);
-    sweeps += sdp_jacobi_reg<Q>(g, v);
+    sweeps += sdp_jacobi_reg<Q>(g);
     SDP_TOC(1, t_jac);
     SDP_TIC(t_rest);
+    // singular values = column norms; U = Lc^-T (G V) by back substitution, one column per lane
     int bad = 0;
-    if (tid < q) {
+    double u[Q];
+    {
         double nrm = 0.0;
 #pragma unroll
         for (int k = 0; k < Q; ++k) nrm += g[k] * g[k];
-        if (!(nrm > 0.0)) bad = 1;
-        w.sq[tid] = sqrt(fmax(nrm, 1e-300));
+        if (tid < q) {
+            if (!(nrm > 0.0)) bad = 1;
+            w.sq[tid] = sqrt(fmax(nrm, 1e-300));
+        }
+        double su = 0.0;
 #pragma unroll
-        for (int k = 0; k < Q; ++k) if (k < q) w.V[k * LD + tid] = v[k];
-    }
-    __syncthreads();
-    if (tid < q) {
-        double acc = 0.0;
-        for (int k = 0; k < q; ++k) acc += w.s[k] * w.V[k * LD + tid];
-        w.sv[tid] = acc;
+        for (int k = Q - 1; k >= 0; --k) {
+            double acc = 0.0;
+            if (k < q) {
+                acc = g[k];
+#pragma unroll
+                for (int r = k + 1; r < Q; ++r) if (r < q) acc -= w.S[r * LD + k] * u[r];
+                acc *= w.rc[k];
+            }
+            u[k] = acc;
+            su += acc;
+        }
+        if (tid < q) {
+            w.sv[tid] = su;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) if (k < q) w.X[k * LD + tid] = u[k];
+        }
     }
     bad = __syncthreads_or(bad);
     if (bad) return -INFINITY;
-    for (int e = tid; e < q * q; e += T) {
+    for (int e = tid; e < q * q; e += T) {        // V = W^-T U, kept for the next warm start
         const int i = e / q, a = e - i * q;
-        w.R[i * LD + a] = w.V[i * LD + a] / w.s[i] + gamp * w.sv[a];
+        w.V[i * LD + a] = (w.X[i * LD + a] + gamp * pt[i] * w.sv[a]) / w.s[i];
     }
-    __syncthreads();
-    if (tid < q) {
-        double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * pt[i];
-        w.rp[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < q) {
-        double db = 0.0, bp = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
-            db += r * rs;
-            bp += rs * w.rp[a];
-        }
-        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
-    }
-    __syncthreads();
-    double gval = 0.0;
-    for (int a = 0; a < q; ++a) gval += w.sq[a] - pt[a] * w.dl[a];
+    const double gval = sdp_eval_tail<T>(w, pt, p0);
     SDP_TOC(2, t_rest);
     return gval;
 }
 
-
 template <int T>
-__device__ double sdp_eval(const SdpWork& w, const double* pt, int& sweeps, bool warm) {
+__device__ double sdp_eval(const SdpWork& w, const lds_f64* pt, int& sweeps, bool warm) {
     if constexpr (T == 64) {
         if (w.q <= 8) return sdp_eval_reg<8>(w, pt, sweeps, warm);
         if (w.q <= 16) return sdp_eval_reg<16>(w, pt, sweeps, warm);
@@ -432,15 +462,107 @@ __device__ double sdp_eval(const SdpWork& w, const double* pt, int& sweeps, bool
     }
 }
 
-// ---- Newton direction at the state left by sdp_eval(w.p): w.step = (-hess g)^-1 grad g ----------
-// Returns 0 on success, 1 if -hess g is not numerically positive definite.
+// ================================================================================================
+// Newton direction at the state left by sdp_eval(w.p): w.step = (-hess g)^-1 grad g
+// ================================================================================================
+// A = -hess g = 1/2 (Q_ij - c_i - c_j + c_0) + (B/2)_ij with, for z^{ij}_a = w_ia w_ja,
+//   Q_ij = z^T K z,  c_i = (w_i o m)^T K (w_i o m),  c_0 = (m o m)^T K (m o m).
+// Every quadratic form is one work item; an item keeps its z vector in registers and walks the
+// symmetric K once (fully unrolled when the size is a compile-time constant), so the inner loop
+// has one broadcast LDS read per multiply-add and no dependent-load chains.
+// Overwrites w.X (w_i), w.Kt (K), w.H (factor), w.ci, w.tv, w.step; keeps w.V.
+// Returns 0 on success, 1 if A is not numerically positive definite.
+template <int Q>
+__device__ __forceinline__ double sdp_quadform_reg(const double (&z)[Q], const lds_f64* Kt, int LD, int q) {
+    double tot = 0.0;
+#pragma unroll
+    for (int a = 0; a < Q; ++a) {
+        if (a < q) {
+            double inner = 0.5 * Kt[a * LD + a] * z[a];
+#pragma unroll
+            for (int b = 0; b < a; ++b) inner += Kt[a * LD + b] * z[b];
+            tot += z[a] * inner;
+        }
+    }
+    return 2.0 * tot;
+}
+
+template <int T, int Q>
+__device__ void sdp_hess_items(const SdpWork& w) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const lds_f64* Wv = w.X;
+    const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
+    for (int e = tid; e < nitems; e += T) {
+        double z[Q];
+        if (e < npair) {
+            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            const int j = e - i * (i + 1) / 2;
+            double bh = 0.0;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                z[a] = (a < q) ? Wv[i * LD + a] * Wv[j * LD + a] : 0.0;
+                if (a < q) bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
+            }
+            w.H[i * LD + j] = 0.5 * sdp_quadform_reg<Q>(z, w.Kt, LD, q) + bh;
+        } else if (e < npair + q) {
+            const int i = e - npair;
+#pragma unroll
+            for (int a = 0; a < Q; ++a) z[a] = (a < q) ? Wv[i * LD + a] * (w.sq[a] * w.rp[a]) : 0.0;
+            w.ci[i] = 0.5 * sdp_quadform_reg<Q>(z, w.Kt, LD, q);
+        } else {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) { const double m = (a < q) ? w.sq[a] * w.rp[a] : 0.0; z[a] = m * m; }
+            w.tv[0] = 0.5 * sdp_quadform_reg<Q>(z, w.Kt, LD, q);
+        }
+    }
+}
+
+// generic-size fallback of the same items (LDS variant)
+template <int T>
+__device__ void sdp_hess_items_lds(const SdpWork& w) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const lds_f64* Wv = w.X;
+    const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
+    for (int e = tid; e < nitems; e += T) {
+        int i = 0, j = 0, kind = 2;
+        if (e < npair) {
+            i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            j = e - i * (i + 1) / 2;
+            kind = 0;
+        } else if (e < npair + q) { i = e - npair; kind = 1; }
+        double tot = 0.0, bh = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double ma = w.sq[a] * w.rp[a];
+            const double za = kind == 0 ? Wv[i * LD + a] * Wv[j * LD + a] : kind == 1 ? Wv[i * LD + a] * ma : ma * ma;
+            double inner = 0.5 * w.Kt[a * LD + a] * za;
+#pragma unroll 4
+            for (int b = 0; b < a; ++b) {
+                const double mb = w.sq[b] * w.rp[b];
+                const double zb = kind == 0 ? Wv[i * LD + b] * Wv[j * LD + b] : kind == 1 ? Wv[i * LD + b] * mb : mb * mb;
+                inner += w.Kt[a * LD + b] * zb;
+            }
+            tot += za * inner;
+            if (kind == 0) bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
+        }
+        if (kind == 0) w.H[i * LD + j] = tot + bh;
+        else if (kind == 1) w.ci[i] = tot;
+        else w.tv[0] = tot;
+    }
+}
+
 template <int T>
 __device__ int sdp_newton_dir(const SdpWork& w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    double* Wv = w.X;      // eigen-decomposition finished: X is free for reuse (V is kept: it
-                           // seeds the next eigendecomposition)
+    lds_f64* Wv = w.X;      // the decomposition is finished: X is free for reuse
     __syncthreads();
+    SDP_TIC(t_items);
     for (int e = tid; e < q * q; e += T) {
         const int i = e / q, a = e - i * q;
         const double m = w.sq[a] * w.rp[a];
@@ -448,45 +570,28 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         w.Kt[i * LD + a] = 1.0 / (w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
     }
     __syncthreads();
-    // ci[i] = sum_ab K_ab w_ia w_ib m_a m_b ;  c0 = sum_ab K_ab m_a^2 m_b^2 (via tv)
-    if (tid < q) {
-        const int i = tid;
-        double acc = 0.0, acc0 = 0.0;
-        const double mi = w.sq[i] * w.rp[i];
-        for (int a = 0; a < q; ++a) {
-            const double ma = w.sq[a] * w.rp[a];
-            const double wa = Wv[i * LD + a] * ma;
-            double inner = 0.0;
-            for (int b = 0; b < q; ++b) inner += w.Kt[a * LD + b] * Wv[i * LD + b] * (w.sq[b] * w.rp[b]);
-            acc += wa * inner;
-            acc0 += w.Kt[i * LD + a] * ma * ma;
-        }
-        w.ci[i] = acc;
-        w.tv[i] = acc0 * mi * mi;
+    // raw items: H[i][j] = Q_ij/2 + (B/2)_ij, ci = c_i/2, tv[0] = c_0/2
+    if constexpr (T == 64) {
+        if (q <= 8) sdp_hess_items<T, 8>(w);
+        else if (q <= 16) sdp_hess_items<T, 16>(w);
+        else if (q <= 20) sdp_hess_items<T, 20>(w);
+        else sdp_hess_items<T, 32>(w);
+    } else {
+        sdp_hess_items_lds<T>(w);
     }
     __syncthreads();
-    double c0 = 0.0;
-    for (int i = 0; i < q; ++i) c0 += w.tv[i];
-    // A = -hess = 1/2 (Q - ci - cj + c0) + B/2, lower triangle;  B/2 = R sq R^T
+    const double c0 = w.tv[0];
     const int npair = q * (q + 1) / 2;
     for (int e = tid; e < npair; e += T) {
-        // unrank e -> (i >= j)
         int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
         const int j = e - i * (i + 1) / 2;
-        double Q = 0.0, bh = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double za = Wv[i * LD + a] * Wv[j * LD + a];
-            double inner = 0.5 * w.Kt[a * LD + a] * za;
-            for (int b = 0; b < a; ++b) inner += w.Kt[a * LD + b] * (Wv[i * LD + b] * Wv[j * LD + b]);
-            Q += za * inner;
-            bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
-        }
-        Q *= 2.0;
-        w.H[i * LD + j] = 0.5 * (Q - w.ci[i] - w.ci[j] + c0) + bh;
+        w.H[i * LD + j] += c0 - w.ci[i] - w.ci[j];
     }
     __syncthreads();
+    SDP_TOC(4, t_items);
+    SDP_TIC(t_chol);
     // in-place Cholesky of A (lower) and solve A step = grad
     int fail = 0;
     for (int k = 0; k < q; ++k) {
@@ -505,6 +610,8 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         __syncthreads();
     }
     if (fail) return 1;
+    SDP_TOC(5, t_chol);
+    SDP_TIC(t_tri);
     if (tid < q) w.step[tid] = w.grad[tid];
     __syncthreads();
     for (int k = 0; k < q; ++k) {          // forward: L y = grad
@@ -521,11 +628,14 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
         __syncthreads();
     }
+    SDP_TOC(6, t_tri);
     return 0;
 }
 
-// ---- full solve.  On entry w.S (symmetric) and w.dl are set.  On exit w.p holds the optimum and
-// the eigen-state (V, sq, R, rp, s) belongs to it.  Returns status; *g_out = max g. ---------------
+// ================================================================================================
+// Full solve.  On entry w.S (symmetric) and w.dl are set.  On exit w.p holds the optimum and the
+// state (X = U, sv, sq, R, rp, s) belongs to it.  Returns status; *g_out = max g.
+// ================================================================================================
 template <int T>
 __device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
     const int tid = threadIdx.x;
@@ -544,7 +654,7 @@ __device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
     __syncthreads();
     int sweeps = 0, it = 0, status = 1;
 #ifdef OEI_SDP_TIMING
-    if (tid == 0) { w.scal[0] = w.scal[1] = w.scal[2] = w.scal[3] = 0.0; }
+    if (tid == 0) { for (int i = 0; i < 8; ++i) w.scal[i] = 0.0; }
 #endif
     if (sdp_factor<T>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
     double g = sdp_eval<T>(w, w.p, sweeps, false);
@@ -589,30 +699,23 @@ __device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
 
 // ---- outputs from the final state ---------------------------------------------------------------
 // Writes N = B^-1 into w.H and c into w.ci, (N c) into w.tv; returns nu = c^T N c.
-// Needs w.V, w.s, w.sq, w.sv, w.R, w.rp of the optimum; `mu` in LDS.
+// Needs w.X = U, w.sq, w.R, w.rp of the optimum; `mu` in LDS.
 template <int T>
-__device__ double sdp_primal(const SdpWork& w, const double* mu) {
+__device__ double sdp_primal(const SdpWork& w, const lds_f64* mu) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    double sum = 0.0;
-    for (int i = 0; i < q; ++i) sum += w.p[i];
-    const double gam = 1.0 / (1.0 + sqrt(1.0 - sum));
-    double* U = w.X;
+    const lds_f64* U = w.X;
     __syncthreads();
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, a = e - i * q;
-        U[i * LD + a] = w.s[i] * w.V[i * LD + a] - gam * w.p[i] * w.sv[a];
-    }
     if (tid < q) {     // c = mu + B p / 2 = mu + R (sq * rp)
         double acc = 0.0;
         for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * w.rp[a];
         w.ci[tid] = mu[tid] + acc;
     }
-    __syncthreads();
     for (int e = tid; e < q * q; e += T) {
         const int i = e / q, j = e - i * q;
         if (j > i) continue;
         double acc = 0.0;
+#pragma unroll 4
         for (int a = 0; a < q; ++a) acc += U[i * LD + a] * U[j * LD + a] / w.sq[a];
         w.H[i * LD + j] = 0.5 * acc;
         w.H[j * LD + i] = 0.5 * acc;

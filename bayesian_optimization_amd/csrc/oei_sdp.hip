@@ -11,7 +11,7 @@ __global__ __launch_bounds__(T) void k_sdp_omega(int q, const double* __restrict
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q);
-    double* mu = sm + sdp_work_doubles(q);          // [q]
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q);          // [q]
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int k_ = q + 1, LD = w.LD;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(T) void k_sdp_omega(int q, const double* __restrict
     if (tid == 0) { value[b] = -w0 * g; status[b] = st; if (iters) iters[b] = it; }
 #ifdef OEI_SDP_TIMING
     __syncthreads();
-    if (tid < 4) M[(size_t)b * k_ * k_ + tid] = w.scal[tid];     // diagnostic build: phase cycles
+    if (tid < 8 && tid < k_ * k_) M[(size_t)b * k_ * k_ + tid] = w.scal[tid];     // diagnostic build: phase cycles
 #endif
 }
 

@@ -21,11 +21,11 @@
 #include "oei_sdp.cuh"
 
 struct SensVec {
-    double *dmu, *dp, *rd, *t1, *t2, *dc, *w1, *w2, *c;   // each sdp_vlen(q) long
+    lds_f64 *dmu, *dp, *rd, *t1, *t2, *dc, *w1, *w2, *c;   // each sdp_vlen(q) long
 };
 #define SENS_NVEC 9
 
-__device__ inline void sens_carve(SensVec& sv, double* base, int q) {
+__device__ inline void sens_carve(SensVec& sv, lds_f64* base, int q) {
     const int VL = sdp_vlen(q);
     sv.dmu = base;           sv.dp = base + VL;      sv.rd = base + 2 * VL;
     sv.t1 = base + 3 * VL;   sv.t2 = base + 4 * VL;  sv.dc = base + 5 * VL;
@@ -35,16 +35,13 @@ __device__ inline void sens_carve(SensVec& sv, double* base, int q) {
 // After sdp_eval at the optimum w.p: store U in w.S, factor -hess g in w.H (lower Cholesky),
 // c in sv.c, t1 = sq o rp.  Leaves w.X, w.V, w.Kt free.  Returns non-zero on breakdown.
 template <int T>
-__device__ int sens_prepare(const SdpWork& w, const double* mu, const SensVec& sv) {
+__device__ int sens_prepare(const SdpWork& w, const lds_f64* mu, const SensVec& sv) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    double sum = 0.0;
-    for (int i = 0; i < q; ++i) sum += w.p[i];
-    const double gam = 1.0 / (1.0 + sqrt(1.0 - sum));
     __syncthreads();
-    for (int e = tid; e < q * q; e += T) {
+    for (int e = tid; e < q * q; e += T) {         // the evaluation left U in w.X
         const int i = e / q, a = e - i * q;
-        w.S[i * LD + a] = w.s[i] * w.V[i * LD + a] - gam * w.p[i] * w.sv[a];
+        w.S[i * LD + a] = w.X[i * LD + a];
     }
     __syncthreads();
     if (sdp_newton_dir<T>(w)) return 1;
@@ -61,7 +58,7 @@ __device__ int sens_prepare(const SdpWork& w, const double* mu, const SensVec& s
 
 // C[i][j] = sum_k A[i][k] * B[k][j]  (TA: use A[k][i]; TB: use B[j][k])
 template <int T, bool TA, bool TB>
-__device__ __forceinline__ void lds_mm(int q, int LD, const double* A, const double* B, double* C) {
+__device__ __forceinline__ void lds_mm(int q, int LD, const lds_f64* A, const lds_f64* B, lds_f64* C) {
     for (int e = threadIdx.x; e < q * q; e += T) {
         const int i = e / q, j = e - i * q;
         double acc = 0.0;
@@ -78,10 +75,10 @@ template <int T>
 __device__ double sens_direction(const SdpWork& w, const SensVec& sv) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    const double* U = w.S;
-    double* Ta = w.X;
-    double* Tb = w.V;
-    double* Tc = w.Kt;
+    const lds_f64* U = w.S;
+    lds_f64* Ta = w.X;
+    lds_f64* Tb = w.V;
+    lds_f64* Tc = w.Kt;
     __syncthreads();
     lds_mm<T, false, false>(q, LD, Ta, U, Tb);            // Tb = dS U
     __syncthreads();

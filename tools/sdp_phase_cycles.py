@@ -10,9 +10,9 @@ gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mod
 X = np.random.RandomState(1).uniform(-.5, .5, (B, q, 6))
 om = gp.omega(X)
 value, M, _, st, it = sdp_batched(om, gp.fmin, want_Y=False)
-cyc = M.reshape(B, -1)[:, :4].cpu().numpy()
+cyc = M.reshape(B, -1)[:, :8].cpu().numpy()
 it = it.cpu().numpy()
 print('B=%d q=%d  newton %.2f sweeps %.2f' % (B, q, (it & 0xffff).mean(), (it >> 16).mean()))
-for name, c in zip(['eval set-up', 'jacobi', 'eval rest', 'newton dir'], cyc.mean(axis=0)):
+for name, c in zip(['eval set-up', 'jacobi', 'eval rest', 'newton dir', ' hess items', ' cholesky', ' tri solves', '-'], cyc.mean(axis=0)):
     print('%-12s %10.0f cycles' % (name, c))
-print('total        %10.0f cycles' % cyc.sum(axis=1).mean())
+print('total        %10.0f cycles' % cyc[:, :4].sum(axis=1).mean())
