@@ -104,7 +104,7 @@ __device__ inline void sdp_carve(SdpWork& w, double* base, int q) {
 // (qe-1); qe = q rounded up to even, pairs touching the padding index are idle.  For one round the
 // np x np grid of 2x2 blocks X[{i_k,j_k},{i_l,j_l}] <- J_k^T (.) J_l is updated independently.
 template <int T>
-__device__ int sdp_jacobi(const SdpWork& w) {
+__device__ int sdp_jacobi(const SdpWork w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const int qe = q + (q & 1), np = qe >> 1, nm1 = qe - 1;
@@ -188,7 +188,7 @@ __device__ int sdp_jacobi(const SdpWork& w) {
 // Shared tail of both evaluation variants.  In: w.X = U, w.sv = column sums of U, w.sq, pt.
 // Out: w.R, w.rp, w.grad; returns g.
 template <int T>
-__device__ double sdp_eval_tail(const SdpWork& w, const lds_f64* pt, double p0) {
+__device__ double sdp_eval_tail(const SdpWork w, const lds_f64* pt, double p0) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const double ip0 = 1.0 / p0;
@@ -223,7 +223,7 @@ __device__ double sdp_eval_tail(const SdpWork& w, const lds_f64* pt, double p0) 
 // Returns g, or -inf when pt leaves the simplex or X loses positive definiteness numerically.
 // LDS variant: needs w.S = S.  Leaves U in w.X.
 template <int T>
-__device__ double sdp_eval_lds(const SdpWork& w, const lds_f64* pt, int& sweeps) {
+__device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     double sum = 0.0, pmin = INFINITY;
@@ -329,7 +329,7 @@ __device__ int sdp_jacobi_reg(double (&g)[Q]) {
 // In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed), reciprocal
 // diagonal in w.rc.  Only the register variant needs it.  Returns non-zero if S is not PD.
 template <int T>
-__device__ int sdp_factor(const SdpWork& w) {
+__device__ int sdp_factor(const SdpWork w) {
     if (T != 64) return 0;              // the LDS variant keeps S itself
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
@@ -359,48 +359,55 @@ __device__ int sdp_factor(const SdpWork& w) {
 
 // Needs w.S = Lc, w.rc = 1/diag(Lc) (sdp_factor).  With `warm`, w.V holds the right singular
 // vectors of the previous evaluation and seeds this one (G <- G V).  Leaves U in w.X and the new
-// V in w.V.
-template <int Q>
-__device__ double sdp_eval_reg(const SdpWork& w, const lds_f64* pt, int& sweeps, bool warm) {
+// V in w.V.  EXACT: q == Q, the unrolled loops carry no bounds tests and form straight-line code;
+// sched_barrier keeps the scheduler from hoisting every LDS read of such a block to its top.
+template <int Q, bool EXACT>
+__device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
     constexpr int T = 64;
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     SDP_TIC(t_setup);
-    double sum = 0.0, pmin = INFINITY;
-    for (int i = 0; i < q; ++i) { sum += pt[i]; pmin = fmin(pmin, pt[i]); }
+    const bool act = tid < q;
+    const int me = act ? tid : 0;
+    const double pme = pt[me];
+    const double sum = wave_sum(act ? pme : 0.0), pmin = wave_min(act ? pme : INFINITY);
     const double p0 = 1.0 - sum;
     if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
     const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), gamp = gam / sp0;
+    const double sme = sqrt(pme);
     __syncthreads();
-    if (tid < q) {
-        w.s[tid] = sqrt(pt[tid]);
-        double acc = 0.0;                       // m = Lc^T p
-        for (int i = tid; i < q; ++i) acc += w.S[i * LD + tid] * pt[i];
-        w.tv[tid] = acc;
+    {
+        double acc = 0.0;                           // m = Lc^T p (Lc is lower: rows >= column)
+#pragma unroll 4
+        for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
+        if (act) { w.s[tid] = sme; w.tv[tid] = acc; }
     }
     __syncthreads();
     double g[Q];
-    {   // column j of G = s_j (Lc^T e_j - gam m)
-        const double sj = (tid < q) ? w.s[tid] : 0.0;
+    {   // column j of G = s_j (Lc^T e_j - gam m); lanes >= q hold zero columns
+        const double sj = act ? sme : 0.0;
 #pragma unroll
-        for (int k = 0; k < Q; ++k)
-            g[k] = (tid < q && k < q) ? sj * (w.S[tid * LD + k] - gam * w.tv[k]) : 0.0;
+        for (int k = 0; k < Q; ++k) {
+            if (EXACT || k < q) g[k] = sj * (w.S[me * LD + k] - gam * w.tv[k]);
+            else g[k] = 0.0;
+        }
+        if (EXACT) __builtin_amdgcn_sched_barrier(0);
     }
     if (warm) {
-        if (tid < q) {
+        if (act) {
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (k < q) w.X[k * LD + tid] = g[k];
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = g[k];
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < Q; ++k) g[k] = 0.0;
-        if (tid < q) {
 #pragma unroll 2
-            for (int j = 0; j < q; ++j) {
-                const double vj = w.V[j * LD + tid];
+        for (int j = 0; j < q; ++j) {
+            const double vl = w.V[j * LD + me];
+            const double vj = act ? vl : 0.0;
 #pragma unroll
-                for (int k = 0; k < Q; ++k) if (k < q) g[k] += w.X[k * LD + j] * vj;
-            }
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) g[k] += w.X[k * LD + j] * vj;
+            if (EXACT) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -416,7 +423,7 @@ __device__ double sdp_eval_reg(const SdpWork& w, const lds_f64* pt, int& sweeps,
         double nrm = 0.0;
 #pragma unroll
         for (int k = 0; k < Q; ++k) nrm += g[k] * g[k];
-        if (tid < q) {
+        if (act) {
             if (!(nrm > 0.0)) bad = 1;
             w.sq[tid] = sqrt(fmax(nrm, 1e-300));
         }
@@ -424,19 +431,21 @@ __device__ double sdp_eval_reg(const SdpWork& w, const lds_f64* pt, int& sweeps,
 #pragma unroll
         for (int k = Q - 1; k >= 0; --k) {
             double acc = 0.0;
-            if (k < q) {
+            if (EXACT || k < q) {
                 acc = g[k];
 #pragma unroll
-                for (int r = k + 1; r < Q; ++r) if (r < q) acc -= w.S[r * LD + k] * u[r];
+                for (int r = k + 1; r < Q; ++r) if (EXACT || r < q) acc -= w.S[r * LD + k] * u[r];
                 acc *= w.rc[k];
             }
+            asm volatile("" : "+v"(acc));      // keeps the arithmetic here (not sunk behind the loads)
             u[k] = acc;
             su += acc;
+            if (EXACT) __builtin_amdgcn_sched_barrier(0);
         }
-        if (tid < q) {
+        if (act) {
             w.sv[tid] = su;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (k < q) w.X[k * LD + tid] = u[k];
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
         }
     }
     bad = __syncthreads_or(bad);
@@ -450,13 +459,18 @@ __device__ double sdp_eval_reg(const SdpWork& w, const lds_f64* pt, int& sweeps,
     return gval;
 }
 
+template <int Q>
+__device__ __forceinline__ double sdp_eval_q(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
+    return (w.q == Q) ? sdp_eval_reg<Q, true>(w, pt, sweeps, warm) : sdp_eval_reg<Q, false>(w, pt, sweeps, warm);
+}
+
 template <int T>
-__device__ double sdp_eval(const SdpWork& w, const lds_f64* pt, int& sweeps, bool warm) {
+__device__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
     if constexpr (T == 64) {
-        if (w.q <= 8) return sdp_eval_reg<8>(w, pt, sweeps, warm);
-        if (w.q <= 16) return sdp_eval_reg<16>(w, pt, sweeps, warm);
-        if (w.q <= 20) return sdp_eval_reg<20>(w, pt, sweeps, warm);
-        return sdp_eval_reg<32>(w, pt, sweeps, warm);
+        if (w.q <= 8) return sdp_eval_q<8>(w, pt, sweeps, warm);
+        if (w.q <= 16) return sdp_eval_q<16>(w, pt, sweeps, warm);
+        if (w.q <= 20) return sdp_eval_q<20>(w, pt, sweeps, warm);
+        return sdp_eval_q<32>(w, pt, sweeps, warm);
     } else {
         return sdp_eval_lds<T>(w, pt, sweeps);
     }
@@ -472,57 +486,211 @@ __device__ double sdp_eval(const SdpWork& w, const lds_f64* pt, int& sweeps, boo
 // has one broadcast LDS read per multiply-add and no dependent-load chains.
 // Overwrites w.X (w_i), w.Kt (K), w.H (factor), w.ci, w.tv, w.step; keeps w.V.
 // Returns 0 on success, 1 if A is not numerically positive definite.
-template <int Q>
-__device__ __forceinline__ double sdp_quadform_reg(const double (&z)[Q], const lds_f64* Kt, int LD, int q) {
+// Two quadratic forms z0^T K z0, z1^T K z1 in one walk over the lower triangle of K: each
+// broadcast LDS read of K feeds two multiply-adds.  EXACT (q == Q): straight-line code, the reads
+// of row a+1 are issued ahead of the arithmetic of row a.
+template <int Q, bool EXACT>
+__device__ __forceinline__ void sdp_quadform2(const double (&z0)[Q], const double (&z1)[Q],
+                                              const lds_f64* Kt, int LD, int q, double& r0, double& r1) {
+    double t0 = 0.0, t1 = 0.0;
+    if constexpr (EXACT) {
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            const double kaa = 0.5 * Kt[a * LD + a];
+            double i0 = kaa * z0[a], i1 = kaa * z1[a];
+#pragma unroll
+            for (int b = 0; b < a; ++b) {
+                const double kab = Kt[a * LD + b];
+                i0 += kab * z0[b];
+                i1 += kab * z1[b];
+            }
+            t0 += z0[a] * i0;
+            t1 += z1[a] * i1;
+            asm volatile("" : "+v"(t0), "+v"(t1));      // keeps the arithmetic with its reads
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < Q; ++a) {
+            if (a < q) {
+                const double kaa = 0.5 * Kt[a * LD + a];
+                double i0 = kaa * z0[a], i1 = kaa * z1[a];
+#pragma unroll
+                for (int b = 0; b < a; ++b) {
+                    const double kab = Kt[a * LD + b];
+                    i0 += kab * z0[b];
+                    i1 += kab * z1[b];
+                }
+                t0 += z0[a] * i0;
+                t1 += z1[a] * i1;
+            }
+        }
+    }
+    r0 = 2.0 * t0;
+    r1 = 2.0 * t1;
+}
+
+template <int Q, bool EXACT>
+__device__ __forceinline__ double sdp_quadform1(const double (&z)[Q], const lds_f64* Kt, int LD, int q) {
     double tot = 0.0;
 #pragma unroll
     for (int a = 0; a < Q; ++a) {
-        if (a < q) {
+        if (EXACT || a < q) {
             double inner = 0.5 * Kt[a * LD + a] * z[a];
 #pragma unroll
             for (int b = 0; b < a; ++b) inner += Kt[a * LD + b] * z[b];
             tot += z[a] * inner;
+            if (EXACT) { asm volatile("" : "+v"(tot)); __builtin_amdgcn_sched_barrier(0); }
         }
     }
     return 2.0 * tot;
 }
 
-template <int T, int Q>
-__device__ void sdp_hess_items(const SdpWork& w) {
+// z vector of work item e and where its result goes: slot >= 0 -> w.H[slot] (pair (i,j), the
+// returned value is its (B/2)_ij term), slot = -1-i -> w.ci[i] (i == q: c_0), slot = INT_MIN: idle.
+// z = A o B with A, B rows of Wv or the vector m (in w.tv); branch-free, all LDS reads unconditional.
+template <int Q, bool EXACT>
+__device__ __forceinline__ double sdp_item_z(const SdpWork w, int e, int npair, double (&z)[Q], int& slot) {
+    const int q = w.q, LD = w.LD;
+    const bool k0 = e < npair, k1 = !k0 && e < npair + q, k2 = e == npair + q;
+    const int ee = k0 ? e : 0;
+    int i = (int)((sqrtf(8.f * (float)ee + 1.f) - 1.f) * 0.5f);
+    i += ((i + 1) * (i + 2) / 2 <= ee) ? 1 : 0;
+    i -= (i * (i + 1) / 2 > ee) ? 1 : 0;
+    const int j = ee - i * (i + 1) / 2;
+    const int ia = k1 ? e - npair : i;
+    const lds_f64* A = (k0 || k1) ? w.X + ia * LD : w.tv;
+    const lds_f64* B = k0 ? w.X + j * LD : w.tv;
+    const lds_f64* Ri = w.R + i * LD;
+    const lds_f64* Rj = w.R + j * LD;
+    double bh = 0.0;
+#pragma unroll
+    for (int a = 0; a < Q; ++a) {
+        if (EXACT || a < q) {
+            z[a] = A[a] * B[a];
+            bh += Ri[a] * Rj[a] * w.sq[a];
+        } else {
+            z[a] = 0.0;
+        }
+        if (EXACT && (a & 3) == 3) {
+            asm volatile("" : "+v"(bh));          // keeps the sum here (not sunk behind the reads)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    slot = k0 ? i * LD + j : k1 ? -1 - ia : k2 ? -1 - q : INT_MIN;
+    return k0 ? bh : 0.0;
+}
+
+__device__ __forceinline__ void sdp_item_store(const SdpWork w, int slot, double val) {
+    if (slot >= 0) w.H[slot] = val;
+    else if (slot != INT_MIN) w.ci[-1 - slot] = val;
+}
+
+// PAIR: two items per walk over K (twice the z registers).
+template <int T, int Q, bool EXACT, bool PAIR>
+__device__ __noinline__ void sdp_hess_items(const SdpWork w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    const lds_f64* Wv = w.X;
     const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
-    for (int e = tid; e < nitems; e += T) {
-        double z[Q];
-        if (e < npair) {
-            int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            const int j = e - i * (i + 1) / 2;
-            double bh = 0.0;
-#pragma unroll
-            for (int a = 0; a < Q; ++a) {
-                z[a] = (a < q) ? Wv[i * LD + a] * Wv[j * LD + a] : 0.0;
-                if (a < q) bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
-            }
-            w.H[i * LD + j] = 0.5 * sdp_quadform_reg<Q>(z, w.Kt, LD, q) + bh;
-        } else if (e < npair + q) {
-            const int i = e - npair;
-#pragma unroll
-            for (int a = 0; a < Q; ++a) z[a] = (a < q) ? Wv[i * LD + a] * (w.sq[a] * w.rp[a]) : 0.0;
-            w.ci[i] = 0.5 * sdp_quadform_reg<Q>(z, w.Kt, LD, q);
-        } else {
-#pragma unroll
-            for (int a = 0; a < Q; ++a) { const double m = (a < q) ? w.sq[a] * w.rp[a] : 0.0; z[a] = m * m; }
-            w.tv[0] = 0.5 * sdp_quadform_reg<Q>(z, w.Kt, LD, q);
+    if constexpr (PAIR) {
+        for (int e0 = tid; e0 < nitems; e0 += 2 * T) {
+            double z0[Q], z1[Q];
+            int s0, s1;
+            const double b0 = sdp_item_z<Q, EXACT>(w, e0, npair, z0, s0);
+            const double b1 = sdp_item_z<Q, EXACT>(w, e0 + T, npair, z1, s1);
+            double r0, r1;
+            sdp_quadform2<Q, EXACT>(z0, z1, w.Kt, LD, q, r0, r1);
+            sdp_item_store(w, s0, 0.5 * r0 + b0);
+            sdp_item_store(w, s1, 0.5 * r1 + b1);
+        }
+    } else {
+        for (int e0 = tid; e0 < nitems; e0 += T) {
+            double z0[Q];
+            int s0;
+            const double b0 = sdp_item_z<Q, EXACT>(w, e0, npair, z0, s0);
+            sdp_item_store(w, s0, 0.5 * sdp_quadform1<Q, EXACT>(z0, w.Kt, LD, q) + b0);
         }
     }
 }
 
+template <int T, int Q>
+__device__ __forceinline__ void sdp_hess_items_q(const SdpWork w) {
+    if (w.q == Q) sdp_hess_items<T, Q, true, (Q <= 20)>(w);
+    else sdp_hess_items<T, Q, false, (Q <= 20)>(w);
+}
+
+// Cholesky A = L L^T of the lower triangle in w.H and the solve A step = grad inside one wave:
+// lane i keeps row i in registers, pivots and multipliers travel by shuffles.  L is written back
+// to w.H (lower) for later solves.  Returns 1 if A is not numerically positive definite.
+template <int Q, bool EXACT>
+__device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
+    const int lane = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const bool act = lane < q;
+    const int row = act ? lane : 0;
+    double a[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        if (EXACT || k < q) { const double h = w.H[row * LD + k]; a[k] = (act && k <= lane) ? h : 0.0; }
+        else a[k] = 0.0;
+    }
+    double dinv = 0.0;
+    int fail = 0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        if (EXACT || k < q) {
+            const double akk = __shfl(a[k], k, 64);
+            if (!(akk > 0.0)) fail = 1;              // identical in every lane; NaNs flow on
+            const double rinv = rsqrt(akk);
+            const double lik = (lane >= k) ? a[k] * rinv : 0.0;
+            a[k] = lik;
+            if (lane == k) dinv = rinv;
+#pragma unroll
+            for (int j = k + 1; j < Q; ++j) {
+                if (EXACT || j < q) { const double ljk = __shfl(lik, j, 64); a[j] -= lik * ljk; }
+            }
+            if (EXACT) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (fail) return 1;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if ((EXACT || k < q) && k <= lane) w.H[row * LD + k] = a[k];
+    }
+    double bv = act ? w.grad[row] : 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {                    // forward: L y = grad, column oriented
+        if (EXACT || k < q) {
+            const double yk = __shfl(bv * dinv, k, 64);
+            bv = (lane == k) ? yk : bv - a[k] * yk;  // a[k] = 0 in lanes < k
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {                    // column `lane` of L = row of L^T
+        if (EXACT || k < q) { const double h = w.H[k * LD + row]; a[k] = (act && k >= lane) ? h : 0.0; }
+        else a[k] = 0.0;
+    }
+#pragma unroll
+    for (int k = Q - 1; k >= 0; --k) {               // backward: L^T x = y
+        if (EXACT || k < q) {
+            const double xk = __shfl(bv * dinv, k, 64);
+            bv = (lane == k) ? xk : bv - a[k] * xk;  // a[k] = 0 in lanes > k
+        }
+    }
+    if (act) w.step[lane] = bv;
+    __syncthreads();
+    return 0;
+}
+
+template <int Q>
+__device__ __forceinline__ int sdp_chol_solve_q(const SdpWork w) {
+    return (w.q == Q) ? sdp_chol_solve_reg<Q, true>(w) : sdp_chol_solve_reg<Q, false>(w);
+}
+
 // generic-size fallback of the same items (LDS variant)
 template <int T>
-__device__ void sdp_hess_items_lds(const SdpWork& w) {
+__device__ void sdp_hess_items_lds(const SdpWork w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const lds_f64* Wv = w.X;
@@ -552,12 +720,12 @@ __device__ void sdp_hess_items_lds(const SdpWork& w) {
         }
         if (kind == 0) w.H[i * LD + j] = tot + bh;
         else if (kind == 1) w.ci[i] = tot;
-        else w.tv[0] = tot;
+        else w.ci[q] = tot;
     }
 }
 
 template <int T>
-__device__ int sdp_newton_dir(const SdpWork& w) {
+__device__ int sdp_newton_dir(const SdpWork w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     lds_f64* Wv = w.X;      // the decomposition is finished: X is free for reuse
@@ -569,18 +737,19 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         Wv[i * LD + a] = w.R[i * LD + a] * w.sq[a] - m;
         w.Kt[i * LD + a] = 1.0 / (w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
     }
+    if (tid < q) w.tv[tid] = w.sq[tid] * w.rp[tid];        // m
     __syncthreads();
-    // raw items: H[i][j] = Q_ij/2 + (B/2)_ij, ci = c_i/2, tv[0] = c_0/2
+    // raw items: H[i][j] = Q_ij/2 + (B/2)_ij, ci[i] = c_i/2, ci[q] = c_0/2
     if constexpr (T == 64) {
-        if (q <= 8) sdp_hess_items<T, 8>(w);
-        else if (q <= 16) sdp_hess_items<T, 16>(w);
-        else if (q <= 20) sdp_hess_items<T, 20>(w);
-        else sdp_hess_items<T, 32>(w);
+        if (q <= 8) sdp_hess_items_q<T, 8>(w);
+        else if (q <= 16) sdp_hess_items_q<T, 16>(w);
+        else if (q <= 20) sdp_hess_items_q<T, 20>(w);
+        else sdp_hess_items_q<T, 32>(w);
     } else {
         sdp_hess_items_lds<T>(w);
     }
     __syncthreads();
-    const double c0 = w.tv[0];
+    const double c0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
     for (int e = tid; e < npair; e += T) {
         int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
@@ -592,7 +761,16 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
     __syncthreads();
     SDP_TOC(4, t_items);
     SDP_TIC(t_chol);
-    // in-place Cholesky of A (lower) and solve A step = grad
+    // Cholesky of A (lower) and solve A step = grad
+    if constexpr (T == 64) {
+        int f;
+        if (q <= 8) f = sdp_chol_solve_q<8>(w);
+        else if (q <= 16) f = sdp_chol_solve_q<16>(w);
+        else if (q <= 20) f = sdp_chol_solve_q<20>(w);
+        else f = sdp_chol_solve_q<32>(w);
+        SDP_TOC(5, t_chol);
+        return f;
+    }
     int fail = 0;
     for (int k = 0; k < q; ++k) {
         const double akk = w.H[k * LD + k];
@@ -610,7 +788,6 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
         __syncthreads();
     }
     if (fail) return 1;
-    SDP_TOC(5, t_chol);
     SDP_TIC(t_tri);
     if (tid < q) w.step[tid] = w.grad[tid];
     __syncthreads();
@@ -637,7 +814,7 @@ __device__ int sdp_newton_dir(const SdpWork& w) {
 // state (X = U, sv, sq, R, rp, s) belongs to it.  Returns status; *g_out = max g.
 // ================================================================================================
 template <int T>
-__device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
+__device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     // start: the closed-form q = 1 weights, shrunk into the simplex
@@ -701,7 +878,7 @@ __device__ int sdp_solve(const SdpWork& w, double* g_out, int* iters_out) {
 // Writes N = B^-1 into w.H and c into w.ci, (N c) into w.tv; returns nu = c^T N c.
 // Needs w.X = U, w.sq, w.R, w.rp of the optimum; `mu` in LDS.
 template <int T>
-__device__ double sdp_primal(const SdpWork& w, const lds_f64* mu) {
+__device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const lds_f64* U = w.X;

@@ -3,7 +3,7 @@
 #include "oei_sdp.cuh"
 
 template <int T>
-__global__ __launch_bounds__(T) void k_sdp_omega(int q, const double* __restrict__ omega,
+__global__ __launch_bounds__(T, 2) void k_sdp_omega(int q, const double* __restrict__ omega,
                                                  const double* __restrict__ fmin,
                                                  double* __restrict__ value, double* __restrict__ M,
                                                  double* __restrict__ Y, int* __restrict__ status,

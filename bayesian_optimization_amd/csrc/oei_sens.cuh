@@ -35,7 +35,7 @@ __device__ inline void sens_carve(SensVec& sv, lds_f64* base, int q) {
 // After sdp_eval at the optimum w.p: store U in w.S, factor -hess g in w.H (lower Cholesky),
 // c in sv.c, t1 = sq o rp.  Leaves w.X, w.V, w.Kt free.  Returns non-zero on breakdown.
 template <int T>
-__device__ int sens_prepare(const SdpWork& w, const lds_f64* mu, const SensVec& sv) {
+__device__ int sens_prepare(const SdpWork w, const lds_f64* mu, const SensVec sv) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     __syncthreads();
@@ -72,7 +72,7 @@ __device__ __forceinline__ void lds_mm(int q, int LD, const lds_f64* A, const ld
 // One direction.  In: sv.dmu, dS (symmetric) in w.X.  Out: dN in w.X, sv.w1 = N dc, sv.w2 = dN c,
 // sv.dp, Z in w.Kt; returns dnu.  dM11 = -dN, dM[:q,q] = w1 + w2, dM[q][q] = -dnu.
 template <int T>
-__device__ double sens_direction(const SdpWork& w, const SensVec& sv) {
+__device__ double sens_direction(const SdpWork w, const SensVec sv) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const lds_f64* U = w.S;
