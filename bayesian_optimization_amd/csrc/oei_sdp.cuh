@@ -43,6 +43,14 @@
 
 // Pointers into LDS carry their address space in the type: pointers that pass through a struct
 // would otherwise degrade to generic (flat) accesses, which are several times slower than ds_*.
+// Inside one scheduling region: issue the LDS reads (up to nr) back to back, then the arithmetic,
+// and close the region.  Without this the register-pressure heuristic of the scheduler tends to
+// emit read / wait / use triples, which exposes the full LDS latency on every element.
+#define SDP_READS_FIRST(nr, nv) do { \
+        __builtin_amdgcn_sched_group_barrier(0x100, (nr), 0); \
+        __builtin_amdgcn_sched_group_barrier(0x002, (nv), 0); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) int lds_i32;
 
@@ -277,15 +285,43 @@ __device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) 
 // ================================================================================================
 // Register variant (one 64-lane wave, q <= Q <= 32)
 // ================================================================================================
+// Reciprocal and reciprocal square root from the hardware seeds (about 2^-23 relative) plus two
+// Newton steps: within a few ulp, a third of the instructions of the correctly rounded forms.
+// Arguments here are positive and far from the ends of the exponent range.
+__device__ __forceinline__ double sdp_rcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-a, x, 1.0);
+    return fma(x, e, x);
+}
+__device__ __forceinline__ double sdp_rsq(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    double e = fma(-(a * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(a * y), y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+// value of lane k (k uniform) in every lane, through the scalar unit instead of the LDS crossbar
+__device__ __forceinline__ double sdp_lane_bcast(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
 // One-sided Jacobi: lane j owns column j of G.  Pairs of a round exchange columns with wave
-// shuffles; a rotation needs alpha = |g_i|^2, beta = |g_j|^2, gamma = g_i . g_j only.  Q is the
-// padded size (even); columns >= q are zero and never rotate.  Returns the number of sweeps.
+// shuffles; a rotation needs alpha = |g_i|^2, beta = |g_j|^2, gamma = g_i . g_j only.  The squared
+// norms are carried along (alpha_i -= t gamma, alpha_j += t gamma) and recomputed once per sweep.
+// Q is the padded size (even); columns >= q are zero and never rotate.  Returns the sweep count.
 template <int Q>
 __device__ int sdp_jacobi_reg(double (&g)[Q]) {
     const int lane = threadIdx.x & 63;
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
         bool rotated = false;
+        double alpha = 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) alpha += g[k] * g[k];
         for (int r = 0; r < Q - 1; ++r) {
             int partner = lane;
             if (lane < Q - 1) {
@@ -296,24 +332,28 @@ __device__ int sdp_jacobi_reg(double (&g)[Q]) {
                 partner = r;
             }
             double pg[Q];
-            double alpha = 0.0, gamma = 0.0;
+            double gamma = 0.0;
 #pragma unroll
             for (int k = 0; k < Q; ++k) pg[k] = __shfl(g[k], partner, 64);
-#pragma unroll
-            for (int k = 0; k < Q; ++k) { alpha += g[k] * g[k]; gamma += g[k] * pg[k]; }
             const double beta = __shfl(alpha, partner, 64);
+#pragma unroll
+            for (int k = 0; k < Q; ++k) gamma += g[k] * pg[k];
             const bool low = lane < partner;
-            const double ai = low ? alpha : beta, aj = low ? beta : alpha;
             double c = 1.0, sg = 0.0;
-            const double g2 = gamma * gamma, aa = ai * aj;
+            const double g2 = gamma * gamma, aa = alpha * beta;
             const bool rot = (lane < Q) && (partner != lane) &&
                              (g2 > SDP_JACOBI_TOL * SDP_JACOBI_TOL * aa);
             if (rot) {
-                const double zeta = (aj - ai) / (2.0 * gamma);
-                double t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                if (zeta < 0.0) t = -t;
-                c = 1.0 / sqrt(1.0 + t * t);
-                sg = low ? -t * c : t * c;       // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
+                // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = alpha_j - alpha_i  (i < j)
+                const double d = low ? beta - alpha : alpha - beta;
+                const double x = fma(d, d, 4.0 * g2);
+                const double h = x * sdp_rsq(x);
+                double t = 2.0 * gamma * sdp_rcp(fabs(d) + h);
+                if (d < 0.0) t = -t;
+                c = sdp_rsq(fma(t, t, 1.0));
+                const double ts = low ? -t : t;
+                sg = ts * c;                     // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
+                alpha = fma(ts, gamma, alpha);
             }
             // the iteration converges quadratically: once every rotation of a sweep had
             // |gamma| <= 1e-7 sqrt(alpha beta), what is left afterwards is below the tolerance
@@ -361,26 +401,43 @@ __device__ int sdp_factor(const SdpWork w) {
 // vectors of the previous evaluation and seeds this one (G <- G V).  Leaves U in w.X and the new
 // V in w.V.  EXACT: q == Q, the unrolled loops carry no bounds tests and form straight-line code;
 // sched_barrier keeps the scheduler from hoisting every LDS read of such a block to its top.
+// Lane a ends up with column a of U in registers, so R, V (columns) and rp = colsum(U)/p0 follow
+// without further reductions; only the gradient needs rows of R (through LDS).
 template <int Q, bool EXACT>
 __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
-    constexpr int T = 64;
     const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     SDP_TIC(t_setup);
     const bool act = tid < q;
     const int me = act ? tid : 0;
     const double pme = pt[me];
-    const double sum = wave_sum(act ? pme : 0.0), pmin = wave_min(act ? pme : INFINITY);
+    double sum, pmin;
+    if constexpr (EXACT) {
+        sum = 0.0; pmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) { const double v = pt[k]; sum += v; pmin = fmin(pmin, v); }
+        SDP_READS_FIRST(Q + 1, 4 * Q);
+    } else {
+        sum = wave_sum(act ? pme : 0.0);
+        pmin = wave_min(act ? pme : INFINITY);
+    }
     const double p0 = 1.0 - sum;
     if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
-    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), gamp = gam / sp0;
-    const double sme = sqrt(pme);
-    __syncthreads();
+    const double rsp0 = sdp_rsq(p0), sp0 = p0 * rsp0, ip0 = rsp0 * rsp0;
+    const double gam = sdp_rcp(1.0 + sp0), gamp = gam * rsp0;
+    const double rsme = sdp_rsq(pme), sme = pme * rsme;
+    __syncthreads();                    // earlier readers of the vectors and of X, V are done
     {
-        double acc = 0.0;                           // m = Lc^T p (Lc is lower: rows >= column)
+        double acc = 0.0;               // m = Lc^T p (the strict upper part of Lc is zero)
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) acc += w.S[i * LD + me] * pt[i];
+            SDP_READS_FIRST(2 * Q, 2 * Q);
+        } else {
 #pragma unroll 4
-        for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
-        if (act) { w.s[tid] = sme; w.tv[tid] = acc; }
+            for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
+        }
+        if (act) { w.s[tid] = sme; w.rs[tid] = rsme; w.rt[tid] = rsme * rsme; w.tv[tid] = acc; }
     }
     __syncthreads();
     double g[Q];
@@ -391,7 +448,7 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
             if (EXACT || k < q) g[k] = sj * (w.S[me * LD + k] - gam * w.tv[k]);
             else g[k] = 0.0;
         }
-        if (EXACT) __builtin_amdgcn_sched_barrier(0);
+        if (EXACT) SDP_READS_FIRST(2 * Q, 4 * Q);
     }
     if (warm) {
         if (act) {
@@ -407,7 +464,7 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
             const double vj = act ? vl : 0.0;
 #pragma unroll
             for (int k = 0; k < Q; ++k) if (EXACT || k < q) g[k] += w.X[k * LD + j] * vj;
-            if (EXACT) __builtin_amdgcn_sched_barrier(0);
+            if (EXACT) SDP_READS_FIRST(Q + 1, 2 * Q + 2);
         }
         __syncthreads();
     }
@@ -418,16 +475,14 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
     SDP_TIC(t_rest);
     // singular values = column norms; U = Lc^-T (G V) by back substitution, one column per lane
     int bad = 0;
-    double u[Q];
+    double sqv = 0.0, su = 0.0;
     {
+        double u[Q];
         double nrm = 0.0;
 #pragma unroll
         for (int k = 0; k < Q; ++k) nrm += g[k] * g[k];
-        if (act) {
-            if (!(nrm > 0.0)) bad = 1;
-            w.sq[tid] = sqrt(fmax(nrm, 1e-300));
-        }
-        double su = 0.0;
+        if (act && !(nrm > 0.0)) bad = 1;
+        sqv = sqrt(fmax(nrm, 1e-300));
 #pragma unroll
         for (int k = Q - 1; k >= 0; --k) {
             double acc = 0.0;
@@ -440,21 +495,46 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
             asm volatile("" : "+v"(acc));      // keeps the arithmetic here (not sunk behind the loads)
             u[k] = acc;
             su += acc;
-            if (EXACT) __builtin_amdgcn_sched_barrier(0);
+            if (EXACT) SDP_READS_FIRST(Q, 2 * Q);
         }
         if (act) {
-            w.sv[tid] = su;
+            w.sq[tid] = sqv; w.sv[tid] = su; w.rp[tid] = su * ip0;
+            const double c0 = su * ip0, c1 = gamp * su;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
+            for (int k = 0; k < Q; ++k) {
+                if (EXACT || k < q) {
+                    w.X[k * LD + tid] = u[k];
+                    w.R[k * LD + tid] = fma(u[k], w.rt[k], c0);                   // U / p + colsum / p0
+                    w.V[k * LD + tid] = fma(c1, pt[k], u[k]) * w.rs[k];           // W^-T U
+                }
+                if (EXACT && (k & 3) == 3) SDP_READS_FIRST(12, 32);
+            }
         }
     }
     bad = __syncthreads_or(bad);
     if (bad) return -INFINITY;
-    for (int e = tid; e < q * q; e += T) {        // V = W^-T U, kept for the next warm start
-        const int i = e / q, a = e - i * q;
-        w.V[i * LD + a] = (w.X[i * LD + a] + gamp * pt[i] * w.sv[a]) / w.s[i];
+    {   // grad g = diag(B)/4 - B p/2 - delta with B = 2 R sq R^T: lane i walks row i of R
+        double db = 0.0, bp = 0.0;
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                const double r = w.R[me * LD + a], rs = r * w.sq[a];
+                db += r * rs;
+                bp += rs * w.rp[a];
+                if ((a & 3) == 3) SDP_READS_FIRST(12, 32);
+            }
+        } else {
+#pragma unroll 4
+            for (int a = 0; a < q; ++a) {
+                const double r = w.R[me * LD + a], rs = r * w.sq[a];
+                db += r * rs;
+                bp += rs * w.rp[a];
+            }
+        }
+        if (act) w.grad[tid] = 0.5 * db - bp - w.dl[tid];
     }
-    const double gval = sdp_eval_tail<T>(w, pt, p0);
+    const double gval = wave_sum(act ? sqv - pme * w.dl[me] : 0.0);
+    __syncthreads();
     SDP_TOC(2, t_rest);
     return gval;
 }
@@ -507,7 +587,7 @@ __device__ __forceinline__ void sdp_quadform2(const double (&z0)[Q], const doubl
             t0 += z0[a] * i0;
             t1 += z1[a] * i1;
             asm volatile("" : "+v"(t0), "+v"(t1));      // keeps the arithmetic with its reads
-            __builtin_amdgcn_sched_barrier(0);
+            SDP_READS_FIRST(Q, 4 * Q);
         }
     } else {
 #pragma unroll
@@ -540,7 +620,7 @@ __device__ __forceinline__ double sdp_quadform1(const double (&z)[Q], const lds_
 #pragma unroll
             for (int b = 0; b < a; ++b) inner += Kt[a * LD + b] * z[b];
             tot += z[a] * inner;
-            if (EXACT) { asm volatile("" : "+v"(tot)); __builtin_amdgcn_sched_barrier(0); }
+            if (EXACT) { asm volatile("" : "+v"(tot)); SDP_READS_FIRST(Q, 4 * Q); }
         }
     }
     return 2.0 * tot;
@@ -551,7 +631,7 @@ __device__ __forceinline__ double sdp_quadform1(const double (&z)[Q], const lds_
 // z = A o B with A, B rows of Wv or the vector m (in w.tv); branch-free, all LDS reads unconditional.
 template <int Q, bool EXACT>
 __device__ __forceinline__ double sdp_item_z(const SdpWork w, int e, int npair, double (&z)[Q], int& slot) {
-    const int q = w.q, LD = w.LD;
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const bool k0 = e < npair, k1 = !k0 && e < npair + q, k2 = e == npair + q;
     const int ee = k0 ? e : 0;
     int i = (int)((sqrtf(8.f * (float)ee + 1.f) - 1.f) * 0.5f);
@@ -574,7 +654,7 @@ __device__ __forceinline__ double sdp_item_z(const SdpWork w, int e, int npair, 
         }
         if (EXACT && (a & 3) == 3) {
             asm volatile("" : "+v"(bh));          // keeps the sum here (not sunk behind the reads)
-            __builtin_amdgcn_sched_barrier(0);
+            SDP_READS_FIRST(20, 32);
         }
     }
     slot = k0 ? i * LD + j : k1 ? -1 - ia : k2 ? -1 - q : INT_MIN;
@@ -590,7 +670,7 @@ __device__ __forceinline__ void sdp_item_store(const SdpWork w, int slot, double
 template <int T, int Q, bool EXACT, bool PAIR>
 __device__ __noinline__ void sdp_hess_items(const SdpWork w) {
     const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
     if constexpr (PAIR) {
         for (int e0 = tid; e0 < nitems; e0 += 2 * T) {
@@ -625,7 +705,7 @@ __device__ __forceinline__ void sdp_hess_items_q(const SdpWork w) {
 template <int Q, bool EXACT>
 __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
     const int lane = threadIdx.x;
-    const int q = w.q, LD = w.LD;
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const bool act = lane < q;
     const int row = act ? lane : 0;
     double a[Q];
@@ -634,20 +714,21 @@ __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
         if (EXACT || k < q) { const double h = w.H[row * LD + k]; a[k] = (act && k <= lane) ? h : 0.0; }
         else a[k] = 0.0;
     }
+    if (EXACT) SDP_READS_FIRST(Q, 4 * Q);
     double dinv = 0.0;
     int fail = 0;
 #pragma unroll
     for (int k = 0; k < Q; ++k) {
         if (EXACT || k < q) {
-            const double akk = __shfl(a[k], k, 64);
+            const double akk = sdp_lane_bcast(a[k], k);
             if (!(akk > 0.0)) fail = 1;              // identical in every lane; NaNs flow on
-            const double rinv = rsqrt(akk);
+            const double rinv = sdp_rsq(akk);
             const double lik = (lane >= k) ? a[k] * rinv : 0.0;
             a[k] = lik;
             if (lane == k) dinv = rinv;
 #pragma unroll
             for (int j = k + 1; j < Q; ++j) {
-                if (EXACT || j < q) { const double ljk = __shfl(lik, j, 64); a[j] -= lik * ljk; }
+                if (EXACT || j < q) { const double ljk = sdp_lane_bcast(lik, j); a[j] -= lik * ljk; }
             }
             if (EXACT) __builtin_amdgcn_sched_barrier(0);
         }
@@ -661,7 +742,7 @@ __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
 #pragma unroll
     for (int k = 0; k < Q; ++k) {                    // forward: L y = grad, column oriented
         if (EXACT || k < q) {
-            const double yk = __shfl(bv * dinv, k, 64);
+            const double yk = sdp_lane_bcast(bv * dinv, k);
             bv = (lane == k) ? yk : bv - a[k] * yk;  // a[k] = 0 in lanes < k
         }
     }
@@ -671,10 +752,11 @@ __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
         if (EXACT || k < q) { const double h = w.H[k * LD + row]; a[k] = (act && k >= lane) ? h : 0.0; }
         else a[k] = 0.0;
     }
+    if (EXACT) SDP_READS_FIRST(Q, 4 * Q);
 #pragma unroll
     for (int k = Q - 1; k >= 0; --k) {               // backward: L^T x = y
         if (EXACT || k < q) {
-            const double xk = __shfl(bv * dinv, k, 64);
+            const double xk = sdp_lane_bcast(bv * dinv, k);
             bv = (lane == k) ? xk : bv - a[k] * xk;  // a[k] = 0 in lanes > k
         }
     }
@@ -735,7 +817,7 @@ __device__ int sdp_newton_dir(const SdpWork w) {
         const int i = e / q, a = e - i * q;
         const double m = w.sq[a] * w.rp[a];
         Wv[i * LD + a] = w.R[i * LD + a] * w.sq[a] - m;
-        w.Kt[i * LD + a] = 1.0 / (w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
+        w.Kt[i * LD + a] = sdp_rcp(w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
     }
     if (tid < q) w.tv[tid] = w.sq[tid] * w.rp[tid];        // m
     __syncthreads();
@@ -752,7 +834,7 @@ __device__ int sdp_newton_dir(const SdpWork w) {
     const double c0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
     for (int e = tid; e < npair; e += T) {
-        int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        int i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
         while ((i + 1) * (i + 2) / 2 <= e) ++i;
         while (i * (i + 1) / 2 > e) --i;
         const int j = e - i * (i + 1) / 2;
