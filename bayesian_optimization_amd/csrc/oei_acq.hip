@@ -82,15 +82,15 @@ __device__ void posterior_moments(const SdpWork w, const KernParams& kp, double 
 }
 
 // LDS of the per-candidate kernels: the solver region (with the A-row staging buffers Ac [q][CH+1]
-// and vc [CH] overlaid on the solver's scratch matrices, which are idle while rows are staged),
-// then mu [q+2] and xq [q*d].
+// and vc [CH] overlaid on everything behind w.H, which is idle while rows are staged), then
+// mu [q+2] and xq [q*d].  `full`: six-matrix solver layout (LDS path), else three.
 __host__ __device__ inline size_t acq_stage_doubles(int q) { return (size_t)q * (CH + 1) + CH; }
-__host__ __device__ inline size_t acq_lds_doubles(int q, int d) {
-    return sdp_region_doubles(q, acq_stage_doubles(q)) + (size_t)(q + 2) + (size_t)q * d;
+__host__ __device__ inline size_t acq_lds_doubles(int q, int d, bool full) {
+    return sdp_region_doubles(q, acq_stage_doubles(q), full) + (size_t)(q + 2) + (size_t)q * d;
 }
 
 // ---- omega (oei.py:79-96) ------------------------------------------------------------------------
-template <int T>
+template <int T, int Q>
 __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n, int npad, int q,
                                              const double* __restrict__ Xq,
                                              const double* __restrict__ A,
@@ -98,10 +98,10 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
                                              double* __restrict__ omega) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
-    sdp_carve(w, sm, q);
-    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q));
+    sdp_carve(w, sm, q, Q == 0);
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q), Q == 0);
     lds_f64* xq = mu + q + 2;
-    lds_f64* Ac = w.X;
+    lds_f64* Ac = w.S;
     lds_f64* vc = Ac + q * (CH + 1);
     const int tid = threadIdx.x, b = blockIdx.x, k_ = q + 1, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
 }
 
 // ---- stage 2: moments -> SDP -> value, p, M11, Z = M11 A ------------------------------------------
-template <int T>
-__global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, double fmin, int n,
+template <int T, int Q>
+__global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, double noise, double fmin, int n,
                                               int npad, int q, const double* __restrict__ Xq,
                                               const double* __restrict__ A,
                                               size_t a_cand_stride, size_t a_row_stride,
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
                                               double* __restrict__ Z) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
-    sdp_carve(w, sm, q);
-    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q));
+    sdp_carve(w, sm, q, Q == 0);
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q), Q == 0);
     lds_f64* xq = mu + q + 2;
-    lds_f64* Ac = w.X;
+    lds_f64* Ac = w.S;
     lds_f64* vc = Ac + q * (CH + 1);
     const int tid = threadIdx.x, b = blockIdx.x, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(T) void k_stage2(KernParams kp, double noise, doubl
     __syncthreads();
     double g = 0.0;
     int it = 0;
-    const int st = sdp_solve<T>(w, &g, &it);
+    const int st = sdp_solve<T, Q>(w, &g, &it);
     double* Zrows = Z + (size_t)b * q * npad;
     if (st == 2) {
         if (tid == 0) { value[b] = NAN; status[b] = 2; }
@@ -373,19 +373,17 @@ static int set_lds(K kernel, size_t lds) {
 int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
                       size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
                       double* p_buf, double* M11_buf, double* Z, hipStream_t st) {
-    const size_t lds2 = acq_lds_doubles(q, m->d) * sizeof(double);
     int rc;
     if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("stage2: q=%d exceeds the per-thread accumulator budget", q);
         return OEI_ERR_ARG;
     }
-    if (q <= 32) {
-        if ((rc = set_lds(k_stage2<64>, lds2))) return rc;
-        hipLaunchKernelGGL(k_stage2<64>, dim3(B), dim3(64), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z);
-    } else {
-        if ((rc = set_lds(k_stage2<256>, lds2))) return rc;
-        hipLaunchKernelGGL(k_stage2<256>, dim3(B), dim3(256), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z);
-    }
+#define LAUNCH_STAGE2(T_, Q_) do { \
+        const size_t lds2 = acq_lds_doubles(q, m->d, (Q_) == 0) * sizeof(double); \
+        if ((rc = set_lds(k_stage2<T_, Q_>, lds2))) return rc; \
+        hipLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z); } while (0)
+    SDP_DISPATCH_Q(q, LAUNCH_STAGE2);
+#undef LAUNCH_STAGE2
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }
@@ -411,13 +409,14 @@ extern "C" int oei_omega_batched(oei_model* m, int B, int q, const double* X, do
     hipStream_t st = (hipStream_t)stream;
     rc = cross_factor(m, X, (size_t)B * q, 0, st);
     if (rc) return rc;
-    const size_t lds = acq_lds_doubles(q, m->d) * sizeof(double);
     if (q <= 32) {
-        if ((rc = set_lds(k_omega<64>, lds))) return rc;
-        hipLaunchKernelGGL(k_omega<64>, dim3(B), dim3(64), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
+        const size_t lds = acq_lds_doubles(q, m->d, false) * sizeof(double);
+        if ((rc = set_lds(k_omega<64, 32>, lds))) return rc;
+        hipLaunchKernelGGL((k_omega<64, 32>), dim3(B), dim3(64), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
     } else {
-        if ((rc = set_lds(k_omega<256>, lds))) return rc;
-        hipLaunchKernelGGL(k_omega<256>, dim3(B), dim3(256), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
+        const size_t lds = acq_lds_doubles(q, m->d, true) * sizeof(double);
+        if ((rc = set_lds(k_omega<256, 0>, lds))) return rc;
+        hipLaunchKernelGGL((k_omega<256, 0>), dim3(B), dim3(256), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
     }
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;

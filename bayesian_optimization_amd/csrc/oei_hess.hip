@@ -17,7 +17,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // ================================================================================================
 // stand-alone sensitivity: sdp.solution_derivative (sdp.py:159-206)
 // ================================================================================================
-template <int T>
+template <int T, int Q>
 __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __restrict__ Yin,
                                                const double* __restrict__ fmin,
                                                const double* __restrict__ domega,
@@ -25,9 +25,9 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
                                                int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
-    sdp_carve(w, sm, q);
+    sdp_carve(w, sm, q, true);
     const int VL = sdp_vlen(q), LD = w.LD, k_ = q + 1;
-    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q);
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, true);
     SensVec sv;
     sens_carve(sv, mu + VL, q);
     lds_f64* Sc = mu + VL + SENS_NVEC * VL;            // copy of S (+ mu mu^T) for dw0 != 0
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
     }
     __syncthreads();
     int sweeps = 0;
-    int st = sdp_factor<T>(w) ? 2 : 0;
-    const double g = st ? -INFINITY : sdp_eval<T>(w, w.p, sweeps, false);
+    int st = sdp_factor<T, Q>(w) ? 2 : 0;
+    const double g = st ? -INFINITY : sdp_eval<T, Q>(w, w.p, sweeps, false);
     if (!(g > -INFINITY)) st = 2;
-    if (!st && sens_prepare<T>(w, mu, sv)) st = 2;
+    if (!st && sens_prepare<T, Q>(w, mu, sv)) st = 2;
     if (st) {
         for (size_t e = tid; e < (size_t)k_ * k_ * K; e += T) dM[(size_t)b * k_ * k_ * K + e] = NAN;
         if (dY) for (int e = tid; e < k_ * k_ * k_; e += T) dY[(size_t)b * k_ * k_ * k_ + e] = NAN;
@@ -148,15 +148,15 @@ extern "C" int oei_solution_derivative_batched(int B, int k_, int K, const doubl
     if (!Y || !fmin || !domega || !dM) { oei_set_error("solution_derivative_batched: null pointer"); return OEI_ERR_ARG; }
     if (dY && K != 1) { oei_set_error("solution_derivative_batched: dY needs K == 1 (sdp.py:196)"); return OEI_ERR_ARG; }
     const int q = k_ - 1;
-    const size_t lds = (sdp_work_doubles(q) + (size_t)(1 + SENS_NVEC) * sdp_vlen(q) + (size_t)q * sdp_ld(q)) * sizeof(double);
+    const size_t lds = (sdp_work_doubles(q, true) + (size_t)(1 + SENS_NVEC) * sdp_vlen(q) + (size_t)q * sdp_ld(q)) * sizeof(double);
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (q <= 32) {
-        if ((rc = set_lds_attr(k_soldiff<64>, lds))) return rc;
-        hipLaunchKernelGGL(k_soldiff<64>, dim3(B), dim3(64), lds, st, q, K, Y, fmin, domega, dM, dY, status);
+        if ((rc = set_lds_attr((k_soldiff<64, 32>), lds))) return rc;
+        hipLaunchKernelGGL((k_soldiff<64, 32>), dim3(B), dim3(64), lds, st, q, K, Y, fmin, domega, dM, dY, status);
     } else {
-        if ((rc = set_lds_attr(k_soldiff<256>, lds))) return rc;
-        hipLaunchKernelGGL(k_soldiff<256>, dim3(B), dim3(256), lds, st, q, K, Y, fmin, domega, dM, dY, status);
+        if ((rc = set_lds_attr((k_soldiff<256, 0>), lds))) return rc;
+        hipLaunchKernelGGL((k_soldiff<256, 0>), dim3(B), dim3(256), lds, st, q, K, Y, fmin, domega, dM, dY, status);
     }
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
@@ -259,11 +259,11 @@ __host__ __device__ inline size_t hess_tab_doubles(int q, int d) {
 
 __host__ __device__ inline size_t hess_lds_doubles(int q, int d) {
     // SdpWork + mu[VL] + SensVec + xq + tables(DS | chunk) + dmuT + k1s + k2s + Dg + M11 + dNmu[VL]
-    return sdp_work_doubles(q) + (size_t)(1 + SENS_NVEC + 1) * sdp_vlen(q) + (size_t)q * d +
+    return sdp_work_doubles(q, true) + (size_t)(1 + SENS_NVEC + 1) * sdp_vlen(q) + (size_t)q * d +
            hess_tab_doubles(q, d) + (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
 }
 
-template <int T>
+template <int T, int Q>
 __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double fmin, int n,
                                             int npad, int q, int RP,
                                             const double* __restrict__ Xtrain,
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
                                             double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
-    sdp_carve(w, sm, q);
+    sdp_carve(w, sm, q, true);
     const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d, dl = (d + 1) | 1;
-    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q);
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, true);
     SensVec sv;
     sens_carve(sv, mu + VL, q);
     lds_f64* dNmu = mu + VL + SENS_NVEC * VL;    // [VL]
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
     }
     __syncthreads();
     int sweeps = 0;
-    int st = sdp_factor<T>(w) ? 2 : 0;
-    const double g = st ? -INFINITY : sdp_eval<T>(w, w.p, sweeps, false);
+    int st = sdp_factor<T, Q>(w) ? 2 : 0;
+    const double g = st ? -INFINITY : sdp_eval<T, Q>(w, w.p, sweeps, false);
     if (!(g > -INFINITY)) st = 2;
-    if (!st && sens_prepare<T>(w, mu, sv)) st = 2;
+    if (!st && sens_prepare<T, Q>(w, mu, sv)) st = 2;
     if (st) {
         for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
         if (tid == 0 && status) status[b] = 2;
@@ -532,11 +532,11 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         double* Hc = H + (size_t)b0 * qd * qd;
         int* sc = status ? status + b0 : nullptr;
         if (q <= 32) {
-            if ((rc = set_lds_attr(k_hess<64>, lds))) return rc;
-            hipLaunchKernelGGL(k_hess<64>, dim3(Bc), dim3(64), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
+            if ((rc = set_lds_attr((k_hess<64, 32>), lds))) return rc;
+            hipLaunchKernelGGL((k_hess<64, 32>), dim3(Bc), dim3(64), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
         } else {
-            if ((rc = set_lds_attr(k_hess<256>, lds))) return rc;
-            hipLaunchKernelGGL(k_hess<256>, dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
+            if ((rc = set_lds_attr((k_hess<256, 0>), lds))) return rc;
+            hipLaunchKernelGGL((k_hess<256, 0>), dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
         }
         OEI_HIP_CHECK(hipGetLastError());
     }

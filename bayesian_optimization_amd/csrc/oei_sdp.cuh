@@ -15,24 +15,29 @@
 //
 //   W = diag(s) (I - gamma 1 p^T),  s = sqrt(p),  gamma = 1/(1 + sqrt(p0)),  S = Lc Lc^T
 //   G = Lc^T W^T,  G V = (orthogonal columns of norms sq),  U = W^T V = Lc^-T (G V),
-//   R = W^-1 V = D^-1 U = U / p + 1 (1^T U) / p0
+//   R = W^-1 V = D^-1 U = U / p + 1 rp^T,  rp = R^T p = (1^T U) / p0
 //   B = 2 R diag(sq) R^T,   N = B^-1 = 1/2 U diag(1/sq) U^T
-//   grad g = diag(B)/4 - B p/2 - delta
+//   grad g = diag(B)/4 - B p/2 - delta  =  (sum_a sq_a U_ia^2) / (2 p_i^2) - (sum_a sq_a rp_a^2)/2 - delta_i
 //   hess g = -1/2 sum_ab K_ab E_i,ab E_j,ab - B/2,   K_ab = 1/(sq_a sq_b (sq_a + sq_b)),
-//            E_i = w_i w_i^T - m m^T,  u_i = sq * R[i,:],  m = sum p_i u_i,  w_i = u_i - m
+//            E_i = w_i w_i^T - m m^T,  w_i = sq o (R[i,:] - rp) = sq o U[i,:] / p_i,  m = sq o rp
 //   M = -[[N, -N c], [-(N c)^T, c^T N c]],  c = mu + B p / 2
 //   y_0 = sqrt(w0 p0) [c; 1],  y_i = sqrt(w0 p_i) [c - B e_i / 2; 1],  Y_i = y_i y_i^T
 //
-// Two implementations of the decomposition:
-//   * q <= 32, one 64-lane wave: one-sided (Hestenes) Jacobi with lane j holding column j of G in
-//     registers; the pairs of a round exchange columns with wave shuffles, no LDS traffic and no
-//     eigenvector accumulation (U follows from a triangular solve with Lc).  The previous U seeds
-//     the next evaluation (G <- G V_prev), which saves sweeps as the Newton steps shrink.
-//   * larger q, 256 threads: two-sided Jacobi on X in LDS, rotations applied as independent 2x2
-//     blocks.
+// Two implementations:
+//   * register path (q <= Q <= 32, one 64-lane wave, template parameter Q > 0): one-sided
+//     (Hestenes) Jacobi with lane j holding column j of G in registers; the pairs of a round
+//     exchange columns with wave shuffles, no LDS traffic and no eigenvector accumulation (U
+//     follows from a triangular solve with Lc).  The previous U seeds the next evaluation
+//     (G <- G V_prev), which saves sweeps as the Newton steps shrink.  Everything the Newton step
+//     needs is expressed through U, so three q x q matrices of LDS suffice (Lc, U and one that
+//     holds the Hessian in its lower and the Loewner kernel in its upper triangle): the small
+//     footprint is what lets ten and more candidates share a compute unit.
+//   * LDS path (larger q, 256 threads, Q = 0): two-sided Jacobi on X in LDS, rotations applied as
+//     independent 2x2 blocks; six matrices.
 // All matrices are q x q with an odd leading dimension LD so that row and column walks are free
 // of LDS bank conflicts.  Every thread of the workgroup executes every call (barriers inside).
 #pragma once
+#include <climits>
 #include "oei_common.h"
 
 #define SDP_MAX_NEWTON 60
@@ -41,8 +46,6 @@
 #define SDP_STEP_TOL 1e-7
 #define SDP_JACOBI_FINAL 1e-7
 
-// Pointers into LDS carry their address space in the type: pointers that pass through a struct
-// would otherwise degrade to generic (flat) accesses, which are several times slower than ds_*.
 // Inside one scheduling region: issue the LDS reads (up to nr) back to back, then the arithmetic,
 // and close the region.  Without this the register-pressure heuristic of the scheduler tends to
 // emit read / wait / use triples, which exposes the full LDS latency on every element.
@@ -51,12 +54,14 @@
         __builtin_amdgcn_sched_group_barrier(0x002, (nv), 0); \
         __builtin_amdgcn_sched_barrier(0); } while (0)
 
+// Pointers into LDS carry their address space in the type: pointers that pass through a struct
+// would otherwise degrade to generic (flat) accesses, which are several times slower than ds_*.
 typedef __attribute__((address_space(3))) double lds_f64;
 typedef __attribute__((address_space(3))) int lds_i32;
 
-// Diagnostic build only (-DOEI_SDP_TIMING): cycle counters per solver phase in w.scal[0..3]
+// Diagnostic build only (-DOEI_SDP_TIMING): cycle counters per solver phase in w.scal[0..6]
 // (0 set-up of an evaluation, 1 Jacobi, 2 rest of the evaluation, 3 Newton direction, of which
-// 4 Hessian assembly, 5 Cholesky, 6 triangular solves).
+// 4 Hessian assembly, 5 Cholesky and solves).
 #ifdef OEI_SDP_TIMING
 #define SDP_TIC(var) const long long var = clock64()
 #define SDP_TOC(slot, var) do { if (threadIdx.x == 0) w.scal[slot] += (double)(clock64() - (var)); } while (0)
@@ -65,48 +70,87 @@ typedef __attribute__((address_space(3))) int lds_i32;
 #define SDP_TOC(slot, var)
 #endif
 
+// The struct is passed BY VALUE everywhere: a reference would live in private memory and every
+// LDS store would force the pointers to be reloaded from there.
 struct SdpWork {
     int q, LD;
-    lds_f64 *S, *X, *V, *R, *H, *Kt;                                // q x LD matrices
-    lds_f64 *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci;  // vectors (length q)
-    lds_f64 *rc, *rs, *rt;                                          // rotation parameters / scratch
+    lds_f64 *H, *S, *X;                   // q x LD matrices, both layouts
+    lds_f64 *V, *R, *Kt;                  // full layout only (LDS path, sensitivity kernels)
+    lds_f64 *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci, *ip, *wp;   // vectors
+    lds_f64 *rc, *rs, *rt;                // 1/diag(Lc) | 1/s or rotation parameters (LDS path)
     lds_i32 *ri, *rj;
-    lds_f64 *scal;                                                  // [8] scalars
+    lds_f64 *scal;                        // [8] scalars
 };
+#define SDP_NVEC 16
 
 __host__ __device__ inline int sdp_ld(int q) { return q | 1; }
 __host__ __device__ inline int sdp_vlen(int q) { return (q + 3) & ~1; }   // even, >= q + 2
 
-__host__ __device__ inline size_t sdp_work_doubles(int q) {
+__host__ __device__ inline size_t sdp_work_doubles(int q, bool full) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
-    return (size_t)6 * q * LD + (size_t)11 * VL + 3 * VL + VL /* ri,rj as ints */ + 8;
+    return (size_t)(full ? 6 : 3) * q * LD + (size_t)SDP_NVEC * VL + VL /* ri,rj as ints */ + 8;
 }
 
-// Callers may use the block starting at w.X (X, V, R, Kt and whatever follows) as a staging buffer
-// of `stage` doubles while no solver state is live.  Size of the region that must be reserved:
-__host__ __device__ inline size_t sdp_region_doubles(int q, size_t stage) {
-    const size_t work = sdp_work_doubles(q), alt = (size_t)2 * q * sdp_ld(q) + stage;
-    return work > alt ? work : alt;
+// Callers may use everything behind w.H (starting at w.S) as a staging buffer of `stage` doubles
+// while no solver state other than w.H is live.  Size of the region that must be reserved:
+__host__ __device__ inline size_t sdp_region_doubles(int q, size_t stage, bool full) {
+    const size_t h = (size_t)q * sdp_ld(q), rest = sdp_work_doubles(q, full) - h;
+    return h + (rest > stage ? rest : stage);
 }
 
-__device__ inline void sdp_carve(SdpWork& w, double* base, int q) {
+__device__ inline void sdp_carve(SdpWork& w, double* base, int q, bool full) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
     w.q = q; w.LD = LD;
     lds_f64* ptr = (lds_f64*)base;
-    // S and H first: X, V, R, Kt are contiguous so callers can stage through them while the
-    // solver is idle (sdp_region_doubles)
-    w.S = ptr; ptr += q * LD;  w.H = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;
-    w.V = ptr; ptr += q * LD;  w.R = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD;
+    w.H = ptr; ptr += q * LD;  w.S = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;
+    w.V = w.R = w.Kt = nullptr;
+    if (full) { w.V = ptr; ptr += q * LD;  w.R = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD; }
     w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
     w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
-    w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;
-    w.rc = ptr; ptr += VL; w.rs = ptr; ptr += VL;  w.rt = ptr; ptr += VL;
+    w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;  w.ip = ptr; ptr += VL;
+    w.wp = ptr; ptr += VL; w.rc = ptr; ptr += VL;  w.rs = ptr; ptr += VL;  w.rt = ptr; ptr += VL;
     w.ri = (lds_i32*)ptr; w.rj = w.ri + VL; ptr += VL;
     w.scal = ptr;
 }
 
+// R[i][a] from the state both paths leave behind (U in w.X, 1/p in w.ip, rp)
+__device__ __forceinline__ double sdp_R(const SdpWork w, int i, int a) {
+    return fma(w.X[i * w.LD + a], w.ip[i], w.rp[a]);
+}
+
+// Reciprocal and reciprocal square root from the hardware seeds (about 2^-23 relative) plus two
+// Newton steps: within a few ulp, a third of the instructions of the correctly rounded forms.
+// Arguments here are positive and far from the ends of the exponent range.
+__device__ __forceinline__ double sdp_rcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-a, x, 1.0);
+    return fma(x, e, x);
+}
+__device__ __forceinline__ double sdp_rsq(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    double e = fma(-(a * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(a * y), y, 1.0);
+    return fma(0.5 * y, e, y);
+}
+// value of lane k (k uniform) in every lane, through the scalar unit instead of the LDS crossbar
+__device__ __forceinline__ double sdp_lane_bcast(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+// index pair (i >= j) of the e-th entry of a row-major lower triangle
+__device__ __forceinline__ void sdp_tri_index(int e, int& i, int& j) {
+    i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
+    i += ((i + 1) * (i + 2) / 2 <= e) ? 1 : 0;
+    i -= (i * (i + 1) / 2 > e) ? 1 : 0;
+    j = e - i * (i + 1) / 2;
+}
+
 // ================================================================================================
-// LDS variant (any workgroup size): two-sided cyclic Jacobi on w.X, eigenvectors in w.V
+// LDS path (any workgroup size): two-sided cyclic Jacobi on w.X, eigenvectors in w.V
 // ================================================================================================
 // Round-robin ordering: in round r, slot 0 pairs (qe-1, r) and slot k pairs ((r+k), (r-k)) mod
 // (qe-1); qe = q rounded up to even, pairs touching the padding index are idle.  For one round the
@@ -193,43 +237,9 @@ __device__ int sdp_jacobi(const SdpWork w) {
     return sweep;
 }
 
-// Shared tail of both evaluation variants.  In: w.X = U, w.sv = column sums of U, w.sq, pt.
-// Out: w.R, w.rp, w.grad; returns g.
-template <int T>
-__device__ double sdp_eval_tail(const SdpWork w, const lds_f64* pt, double p0) {
-    const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
-    const double ip0 = 1.0 / p0;
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, a = e - i * q;
-        w.R[i * LD + a] = w.X[i * LD + a] / pt[i] + w.sv[a] * ip0;
-    }
-    __syncthreads();
-    if (tid < q) {
-        double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * pt[i];
-        w.rp[tid] = acc;
-    }
-    __syncthreads();
-    if (tid < q) {
-        double db = 0.0, bp = 0.0;
-#pragma unroll 4
-        for (int a = 0; a < q; ++a) {
-            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
-            db += r * rs;
-            bp += rs * w.rp[a];
-        }
-        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
-    }
-    __syncthreads();
-    double g = 0.0;
-    for (int a = 0; a < q; ++a) g += w.sq[a] - pt[a] * w.dl[a];
-    return g;
-}
-
-// ---- evaluate g, grad g and the eigen-state at the point pt (length q, in LDS) ------------------
-// Returns g, or -inf when pt leaves the simplex or X loses positive definiteness numerically.
-// LDS variant: needs w.S = S.  Leaves U in w.X.
+// Evaluate g, grad g and the eigen-state at the point pt (length q, in LDS).  Returns g, or -inf
+// when pt leaves the simplex or X loses positive definiteness numerically.  Needs w.S = S.
+// Leaves U in w.X, R in w.R, and the vectors sq, sv, rp, ip, s, grad.
 template <int T>
 __device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) {
     const int tid = threadIdx.x;
@@ -238,10 +248,11 @@ __device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) 
     for (int i = 0; i < q; ++i) { sum += pt[i]; pmin = fmin(pmin, pt[i]); }
     const double p0 = 1.0 - sum;
     if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
-    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0);
+    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), ip0 = 1.0 / p0;
     __syncthreads();           // previous readers of s/tv/X/V are done
     if (tid < q) {
         w.s[tid] = sqrt(pt[tid]);
+        w.ip[tid] = 1.0 / pt[tid];
         double acc = 0.0;
         for (int j = 0; j < q; ++j) acc += w.S[tid * LD + j] * pt[j];
         w.tv[tid] = acc;
@@ -277,38 +288,118 @@ __device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) 
         double acc = 0.0;
         for (int i = 0; i < q; ++i) acc += w.X[i * LD + tid];
         w.sv[tid] = acc;
+        w.rp[tid] = acc * ip0;
     }
     __syncthreads();
-    return sdp_eval_tail<T>(w, pt, p0);
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        w.R[i * LD + a] = sdp_R(w, i, a);
+    }
+    __syncthreads();
+    if (tid < q) {
+        double db = 0.0, bp = 0.0;
+#pragma unroll 4
+        for (int a = 0; a < q; ++a) {
+            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
+            db += r * rs;
+            bp += rs * w.rp[a];
+        }
+        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
+    }
+    __syncthreads();
+    double g = 0.0;
+    for (int a = 0; a < q; ++a) g += w.sq[a] - pt[a] * w.dl[a];
+    return g;
+}
+
+// Newton direction, LDS path: w.step = (-hess g)^-1 grad g at the state left by sdp_eval_lds.
+// A = -hess g = 1/2 (Q_ij - c_i - c_j + c_0) + (B/2)_ij with, for z^{ij}_a = w_ia w_ja,
+//   Q_ij = z^T K z,  c_i = (w_i o m)^T K (w_i o m),  c_0 = (m o m)^T K (m o m).
+// Overwrites w.X (w_i), w.Kt (K), w.H (factor), w.ci, w.step.  Returns 1 if A is not PD.
+template <int T>
+__device__ int sdp_newton_dir_lds(const SdpWork w) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    lds_f64* Wv = w.X;
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        const double m = w.sq[a] * w.rp[a];
+        Wv[i * LD + a] = w.R[i * LD + a] * w.sq[a] - m;
+        w.Kt[i * LD + a] = 1.0 / (w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
+    }
+    __syncthreads();
+    const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
+    for (int e = tid; e < nitems; e += T) {
+        int i = 0, j = 0, kind = 2;
+        if (e < npair) { sdp_tri_index(e, i, j); kind = 0; }
+        else if (e < npair + q) { i = e - npair; kind = 1; }
+        double tot = 0.0, bh = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double ma = w.sq[a] * w.rp[a];
+            const double za = kind == 0 ? Wv[i * LD + a] * Wv[j * LD + a] : kind == 1 ? Wv[i * LD + a] * ma : ma * ma;
+            double inner = 0.5 * w.Kt[a * LD + a] * za;
+#pragma unroll 4
+            for (int b = 0; b < a; ++b) {
+                const double mb = w.sq[b] * w.rp[b];
+                const double zb = kind == 0 ? Wv[i * LD + b] * Wv[j * LD + b] : kind == 1 ? Wv[i * LD + b] * mb : mb * mb;
+                inner += w.Kt[a * LD + b] * zb;
+            }
+            tot += za * inner;
+            if (kind == 0) bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
+        }
+        if (kind == 0) w.H[i * LD + j] = tot + bh;
+        else if (kind == 1) w.ci[i] = tot;
+        else w.ci[q] = tot;
+    }
+    __syncthreads();
+    const double c0 = w.ci[q];
+    for (int e = tid; e < npair; e += T) {
+        int i, j;
+        sdp_tri_index(e, i, j);
+        w.H[i * LD + j] += c0 - w.ci[i] - w.ci[j];
+    }
+    __syncthreads();
+    int fail = 0;
+    for (int k = 0; k < q; ++k) {
+        const double akk = w.H[k * LD + k];
+        if (!(akk > 0.0)) { fail = 1; break; }     // identical in every thread
+        const double piv = sqrt(akk);
+        __syncthreads();
+        if (tid == 0) w.H[k * LD + k] = piv;
+        for (int i = k + 1 + tid; i < q; i += T) w.H[i * LD + k] /= piv;
+        __syncthreads();
+        const int rem = q - k - 1;
+        for (int e = tid; e < rem * rem; e += T) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j <= i) w.H[i * LD + j] -= w.H[i * LD + k] * w.H[j * LD + k];
+        }
+        __syncthreads();
+    }
+    if (fail) return 1;
+    if (tid < q) w.step[tid] = w.grad[tid];
+    __syncthreads();
+    for (int k = 0; k < q; ++k) {          // forward: L y = grad
+        const double yk = w.step[k] / w.H[k * LD + k];
+        __syncthreads();
+        if (tid == k) w.step[k] = yk;
+        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
+        __syncthreads();
+    }
+    for (int k = q - 1; k >= 0; --k) {     // backward: L^T x = y
+        const double xk = w.step[k] / w.H[k * LD + k];
+        __syncthreads();
+        if (tid == k) w.step[k] = xk;
+        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
+        __syncthreads();
+    }
+    return 0;
 }
 
 // ================================================================================================
-// Register variant (one 64-lane wave, q <= Q <= 32)
+// Register path (one 64-lane wave, q <= Q <= 32).  EXACT: q == Q, the unrolled loops carry no
+// bounds tests, LD is a constant and the code is straight-line.
 // ================================================================================================
-// Reciprocal and reciprocal square root from the hardware seeds (about 2^-23 relative) plus two
-// Newton steps: within a few ulp, a third of the instructions of the correctly rounded forms.
-// Arguments here are positive and far from the ends of the exponent range.
-__device__ __forceinline__ double sdp_rcp(double a) {
-    double x = __builtin_amdgcn_rcp(a);
-    double e = fma(-a, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-a, x, 1.0);
-    return fma(x, e, x);
-}
-__device__ __forceinline__ double sdp_rsq(double a) {
-    double y = __builtin_amdgcn_rsq(a);
-    double e = fma(-(a * y), y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-(a * y), y, 1.0);
-    return fma(0.5 * y, e, y);
-}
-// value of lane k (k uniform) in every lane, through the scalar unit instead of the LDS crossbar
-__device__ __forceinline__ double sdp_lane_bcast(double v, int k) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-    return __hiloint2double(hi, lo);
-}
-
 // One-sided Jacobi: lane j owns column j of G.  Pairs of a round exchange columns with wave
 // shuffles; a rotation needs alpha = |g_i|^2, beta = |g_j|^2, gamma = g_i . g_j only.  The squared
 // norms are carried along (alpha_i -= t gamma, alpha_j += t gamma) and recomputed once per sweep.
@@ -366,43 +457,63 @@ __device__ int sdp_jacobi_reg(double (&g)[Q]) {
     return sweep;
 }
 
-// In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed), reciprocal
-// diagonal in w.rc.  Only the register variant needs it.  Returns non-zero if S is not PD.
-template <int T>
-__device__ int sdp_factor(const SdpWork w) {
-    if (T != 64) return 0;              // the LDS variant keeps S itself
-    const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
-    __syncthreads();
-    for (int k = 0; k < q; ++k) {
-        const double akk = w.S[k * LD + k];
-        if (!(akk > 0.0)) return 1;     // identical in every thread
-        const double piv = sqrt(akk);
-        __syncthreads();
-        if (tid == 0) { w.S[k * LD + k] = piv; w.rc[k] = 1.0 / piv; }
-        for (int i = k + 1 + tid; i < q; i += T) w.S[i * LD + k] /= piv;
-        __syncthreads();
-        const int rem = q - k - 1;
-        for (int e = tid; e < rem * rem; e += T) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) w.S[i * LD + j] -= w.S[i * LD + k] * w.S[j * LD + k];
+// Cholesky A = L L^T inside one wave: lane i keeps row i (a[k], k <= i, zeros behind) in
+// registers, pivots and multipliers travel through the scalar unit.  On return a[] holds row i of
+// L and dinv = 1/L_ii.  Returns 1 if a pivot is not positive (the arithmetic carries on).
+template <int Q, bool EXACT>
+__device__ __forceinline__ int sdp_chol_rows(double (&a)[Q], double& dinv, int q, int lane) {
+    int fail = 0;
+    dinv = 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        if (EXACT || k < q) {
+            const double akk = sdp_lane_bcast(a[k], k);
+            if (!(akk > 0.0)) fail = 1;              // identical in every lane
+            const double rinv = sdp_rsq(akk);
+            const double lik = (lane >= k) ? a[k] * rinv : 0.0;
+            a[k] = lik;
+            if (lane == k) dinv = rinv;
+#pragma unroll
+            for (int j = k + 1; j < Q; ++j) {
+                if (EXACT || j < q) { const double ljk = sdp_lane_bcast(lik, j); a[j] -= lik * ljk; }
+            }
+            if (EXACT) __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
     }
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, j = e - i * q;
-        if (j > i) w.S[i * LD + j] = 0.0;
-    }
-    __syncthreads();
-    return 0;
+    return fail;
 }
 
-// Needs w.S = Lc, w.rc = 1/diag(Lc) (sdp_factor).  With `warm`, w.V holds the right singular
-// vectors of the previous evaluation and seeds this one (G <- G V).  Leaves U in w.X and the new
-// V in w.V.  EXACT: q == Q, the unrolled loops carry no bounds tests and form straight-line code;
-// sched_barrier keeps the scheduler from hoisting every LDS read of such a block to its top.
-// Lane a ends up with column a of U in registers, so R, V (columns) and rp = colsum(U)/p0 follow
-// without further reductions; only the gradient needs rows of R (through LDS).
+// In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed), reciprocal
+// diagonal in w.rc.  Returns non-zero if S is not PD.
+template <int Q, bool EXACT>
+__device__ __noinline__ int sdp_factor_reg(const SdpWork w) {
+    const int lane = threadIdx.x;
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
+    const bool act = lane < q;
+    const int row = act ? lane : 0;
+    __syncthreads();
+    double a[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        if (EXACT || k < q) { const double h = w.S[row * LD + k]; a[k] = (act && k <= lane) ? h : 0.0; }
+        else a[k] = 0.0;
+    }
+    if (EXACT) SDP_READS_FIRST(Q, 4 * Q);
+    double dinv;
+    const int fail = sdp_chol_rows<Q, EXACT>(a, dinv, q, lane);
+    if (act) {
+        w.rc[lane] = dinv;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.S[row * LD + k] = (k <= lane) ? a[k] : 0.0;
+    }
+    __syncthreads();
+    return fail;
+}
+
+// Needs w.S = Lc, w.rc = 1/diag(Lc) (sdp_factor_reg).  With `warm`, the state of the previous
+// evaluation (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in w.sv) seeds this one:
+// G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
+// Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
 template <int Q, bool EXACT>
 __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
     const int tid = threadIdx.x;
@@ -425,8 +536,9 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
     if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
     const double rsp0 = sdp_rsq(p0), sp0 = p0 * rsp0, ip0 = rsp0 * rsp0;
     const double gam = sdp_rcp(1.0 + sp0), gamp = gam * rsp0;
-    const double rsme = sdp_rsq(pme), sme = pme * rsme;
-    __syncthreads();                    // earlier readers of the vectors and of X, V are done
+    const double rsme = sdp_rsq(pme), sme = pme * rsme, ipme = rsme * rsme;
+    const double rs_prev = w.rs[me], sv_prev = w.sv[me];    // read before this call overwrites them
+    __syncthreads();                    // earlier readers of the vectors are done
     {
         double acc = 0.0;               // m = Lc^T p (the strict upper part of Lc is zero)
         if constexpr (EXACT) {
@@ -437,7 +549,7 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
 #pragma unroll 4
             for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
         }
-        if (act) { w.s[tid] = sme; w.rs[tid] = rsme; w.rt[tid] = rsme * rsme; w.tv[tid] = acc; }
+        if (act) w.tv[tid] = acc;
     }
     __syncthreads();
     double g[Q];
@@ -451,20 +563,21 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
         if (EXACT) SDP_READS_FIRST(2 * Q, 4 * Q);
     }
     if (warm) {
+        lds_f64* GT = w.H;
         if (act) {
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = g[k];
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) GT[k * LD + tid] = g[k] * rs_prev;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < Q; ++k) g[k] = 0.0;
 #pragma unroll 2
         for (int j = 0; j < q; ++j) {
-            const double vl = w.V[j * LD + me];
+            const double vl = fma(sv_prev, w.wp[j], w.X[j * LD + me]);     // s_j V_prev[j][a]
             const double vj = act ? vl : 0.0;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) g[k] += w.X[k * LD + j] * vj;
-            if (EXACT) SDP_READS_FIRST(Q + 1, 2 * Q + 2);
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) g[k] += GT[k * LD + j] * vj;
+            if (EXACT) SDP_READS_FIRST(Q + 2, 2 * Q + 4);
         }
         __syncthreads();
     }
@@ -499,39 +612,32 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
         }
         if (act) {
             w.sq[tid] = sqv; w.sv[tid] = su; w.rp[tid] = su * ip0;
-            const double c0 = su * ip0, c1 = gamp * su;
+            w.s[tid] = sme; w.rs[tid] = rsme; w.ip[tid] = ipme; w.wp[tid] = gamp * pme;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) {
-                if (EXACT || k < q) {
-                    w.X[k * LD + tid] = u[k];
-                    w.R[k * LD + tid] = fma(u[k], w.rt[k], c0);                   // U / p + colsum / p0
-                    w.V[k * LD + tid] = fma(c1, pt[k], u[k]) * w.rs[k];           // W^-T U
-                }
-                if (EXACT && (k & 3) == 3) SDP_READS_FIRST(12, 32);
-            }
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
         }
     }
     bad = __syncthreads_or(bad);
     if (bad) return -INFINITY;
-    {   // grad g = diag(B)/4 - B p/2 - delta with B = 2 R sq R^T: lane i walks row i of R
-        double db = 0.0, bp = 0.0;
+    {   // grad_i = (sum_a sq_a U_ia^2) / (2 p_i^2) - (sum_a sq_a rp_a^2)/2 - delta_i: lane i walks row i of U
+        double d = 0.0;
         if constexpr (EXACT) {
 #pragma unroll
             for (int a = 0; a < Q; ++a) {
-                const double r = w.R[me * LD + a], rs = r * w.sq[a];
-                db += r * rs;
-                bp += rs * w.rp[a];
-                if ((a & 3) == 3) SDP_READS_FIRST(12, 32);
+                const double x = w.X[me * LD + a];
+                d += x * x * w.sq[a];
+                if ((a & 3) == 3) SDP_READS_FIRST(8, 16);
             }
         } else {
 #pragma unroll 4
             for (int a = 0; a < q; ++a) {
-                const double r = w.R[me * LD + a], rs = r * w.sq[a];
-                db += r * rs;
-                bp += rs * w.rp[a];
+                const double x = w.X[me * LD + a];
+                d += x * x * w.sq[a];
             }
         }
-        if (act) w.grad[tid] = 0.5 * db - bp - w.dl[tid];
+        const double rpa = su * ip0;
+        const double t0 = wave_sum(act ? sqv * rpa * rpa : 0.0);
+        if (act) w.grad[tid] = 0.5 * (d * ipme * ipme - t0) - w.dl[tid];
     }
     const double gval = wave_sum(act ? sqv - pme * w.dl[me] : 0.0);
     __syncthreads();
@@ -539,70 +645,36 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
     return gval;
 }
 
-template <int Q>
-__device__ __forceinline__ double sdp_eval_q(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
-    return (w.q == Q) ? sdp_eval_reg<Q, true>(w, pt, sweeps, warm) : sdp_eval_reg<Q, false>(w, pt, sweeps, warm);
-}
-
-template <int T>
-__device__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
-    if constexpr (T == 64) {
-        if (w.q <= 8) return sdp_eval_q<8>(w, pt, sweeps, warm);
-        if (w.q <= 16) return sdp_eval_q<16>(w, pt, sweeps, warm);
-        if (w.q <= 20) return sdp_eval_q<20>(w, pt, sweeps, warm);
-        return sdp_eval_q<32>(w, pt, sweeps, warm);
-    } else {
-        return sdp_eval_lds<T>(w, pt, sweeps);
-    }
-}
-
-// ================================================================================================
-// Newton direction at the state left by sdp_eval(w.p): w.step = (-hess g)^-1 grad g
-// ================================================================================================
-// A = -hess g = 1/2 (Q_ij - c_i - c_j + c_0) + (B/2)_ij with, for z^{ij}_a = w_ia w_ja,
-//   Q_ij = z^T K z,  c_i = (w_i o m)^T K (w_i o m),  c_0 = (m o m)^T K (m o m).
-// Every quadratic form is one work item; an item keeps its z vector in registers and walks the
-// symmetric K once (fully unrolled when the size is a compile-time constant), so the inner loop
-// has one broadcast LDS read per multiply-add and no dependent-load chains.
-// Overwrites w.X (w_i), w.Kt (K), w.H (factor), w.ci, w.tv, w.step; keeps w.V.
-// Returns 0 on success, 1 if A is not numerically positive definite.
-// Two quadratic forms z0^T K z0, z1^T K z1 in one walk over the lower triangle of K: each
-// broadcast LDS read of K feeds two multiply-adds.  EXACT (q == Q): straight-line code, the reads
-// of row a+1 are issued ahead of the arithmetic of row a.
+// ------------------------------------------------------------------------------------------------
+// Newton direction, register path.  With z = U_i o U_j (pair items), U_i o rp, rp o rp and the
+// scaled kernel K'_ab = sq_a sq_b / (sq_a + sq_b) (upper triangle of w.H; K'_aa = sq_a / 2):
+//   qf = z^T K' z,  lf = sq^T z,
+//   A_ij = -hess g_ij = qf/(2 p_i^2 p_j^2) + lf/(p_i p_j) + e_i + e_j + e_0,
+//   e_i = -qf_i/(2 p_i^2) + lf_i/p_i  (z = U_i o rp),   e_0 = qf_0/2 + lf_0  (z = rp o rp).
+// Every quadratic form is one work item; an item keeps its z vector in registers and walks K'
+// once, two items per walk (each broadcast LDS read feeds two multiply-adds).
+// ------------------------------------------------------------------------------------------------
 template <int Q, bool EXACT>
 __device__ __forceinline__ void sdp_quadform2(const double (&z0)[Q], const double (&z1)[Q],
-                                              const lds_f64* Kt, int LD, int q, double& r0, double& r1) {
+                                              const SdpWork w, int LD, int q, double& r0, double& r1) {
     double t0 = 0.0, t1 = 0.0;
-    if constexpr (EXACT) {
+    const lds_f64* Kt = w.H;           // K'(a,b), b < a, at Kt[b * LD + a]
 #pragma unroll
-        for (int a = 0; a < Q; ++a) {
-            const double kaa = 0.5 * Kt[a * LD + a];
+    for (int a = 0; a < Q; ++a) {
+        if (EXACT || a < q) {
+            const double kaa = 0.25 * w.sq[a];
             double i0 = kaa * z0[a], i1 = kaa * z1[a];
 #pragma unroll
             for (int b = 0; b < a; ++b) {
-                const double kab = Kt[a * LD + b];
+                const double kab = Kt[b * LD + a];
                 i0 += kab * z0[b];
                 i1 += kab * z1[b];
             }
             t0 += z0[a] * i0;
             t1 += z1[a] * i1;
-            asm volatile("" : "+v"(t0), "+v"(t1));      // keeps the arithmetic with its reads
-            SDP_READS_FIRST(Q, 4 * Q);
-        }
-    } else {
-#pragma unroll
-        for (int a = 0; a < Q; ++a) {
-            if (a < q) {
-                const double kaa = 0.5 * Kt[a * LD + a];
-                double i0 = kaa * z0[a], i1 = kaa * z1[a];
-#pragma unroll
-                for (int b = 0; b < a; ++b) {
-                    const double kab = Kt[a * LD + b];
-                    i0 += kab * z0[b];
-                    i1 += kab * z1[b];
-                }
-                t0 += z0[a] * i0;
-                t1 += z1[a] * i1;
+            if (EXACT) {
+                asm volatile("" : "+v"(t0), "+v"(t1));      // keeps the arithmetic with its reads
+                SDP_READS_FIRST(Q, 4 * Q);
             }
         }
     }
@@ -611,14 +683,15 @@ __device__ __forceinline__ void sdp_quadform2(const double (&z0)[Q], const doubl
 }
 
 template <int Q, bool EXACT>
-__device__ __forceinline__ double sdp_quadform1(const double (&z)[Q], const lds_f64* Kt, int LD, int q) {
+__device__ __forceinline__ double sdp_quadform1(const double (&z)[Q], const SdpWork w, int LD, int q) {
     double tot = 0.0;
+    const lds_f64* Kt = w.H;
 #pragma unroll
     for (int a = 0; a < Q; ++a) {
         if (EXACT || a < q) {
-            double inner = 0.5 * Kt[a * LD + a] * z[a];
+            double inner = 0.25 * w.sq[a] * z[a];
 #pragma unroll
-            for (int b = 0; b < a; ++b) inner += Kt[a * LD + b] * z[b];
+            for (int b = 0; b < a; ++b) inner += Kt[b * LD + a] * z[b];
             tot += z[a] * inner;
             if (EXACT) { asm volatile("" : "+v"(tot)); SDP_READS_FIRST(Q, 4 * Q); }
         }
@@ -626,49 +699,48 @@ __device__ __forceinline__ double sdp_quadform1(const double (&z)[Q], const lds_
     return 2.0 * tot;
 }
 
-// z vector of work item e and where its result goes: slot >= 0 -> w.H[slot] (pair (i,j), the
-// returned value is its (B/2)_ij term), slot = -1-i -> w.ci[i] (i == q: c_0), slot = INT_MIN: idle.
-// z = A o B with A, B rows of Wv or the vector m (in w.tv); branch-free, all LDS reads unconditional.
+// z vector of work item e, lf = sq^T z, the scale 1/(p_i p_j) and where the result goes:
+// slot >= 0 -> w.H[slot] (pair (i,j)), slot = -1-i -> w.ci[i] (i == q: e_0), INT_MIN: idle.
+// Branch-free; all LDS reads unconditional (idle items read valid rows).
 template <int Q, bool EXACT>
-__device__ __forceinline__ double sdp_item_z(const SdpWork w, int e, int npair, double (&z)[Q], int& slot) {
-    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
+__device__ __forceinline__ void sdp_item_z(const SdpWork w, int LD, int e, int npair, double (&z)[Q],
+                                           double& lf, double& scale, int& slot) {
+    const int q = w.q;
     const bool k0 = e < npair, k1 = !k0 && e < npair + q, k2 = e == npair + q;
-    const int ee = k0 ? e : 0;
-    int i = (int)((sqrtf(8.f * (float)ee + 1.f) - 1.f) * 0.5f);
-    i += ((i + 1) * (i + 2) / 2 <= ee) ? 1 : 0;
-    i -= (i * (i + 1) / 2 > ee) ? 1 : 0;
-    const int j = ee - i * (i + 1) / 2;
+    int i, j;
+    sdp_tri_index(k0 ? e : 0, i, j);
     const int ia = k1 ? e - npair : i;
-    const lds_f64* A = (k0 || k1) ? w.X + ia * LD : w.tv;
-    const lds_f64* B = k0 ? w.X + j * LD : w.tv;
-    const lds_f64* Ri = w.R + i * LD;
-    const lds_f64* Rj = w.R + j * LD;
-    double bh = 0.0;
+    const lds_f64* A = (k0 || k1) ? w.X + ia * LD : w.rp;
+    const lds_f64* B = k0 ? w.X + j * LD : w.rp;
+    double acc = 0.0;
 #pragma unroll
     for (int a = 0; a < Q; ++a) {
         if (EXACT || a < q) {
             z[a] = A[a] * B[a];
-            bh += Ri[a] * Rj[a] * w.sq[a];
+            acc += z[a] * w.sq[a];
         } else {
             z[a] = 0.0;
         }
         if (EXACT && (a & 3) == 3) {
-            asm volatile("" : "+v"(bh));          // keeps the sum here (not sunk behind the reads)
-            SDP_READS_FIRST(20, 32);
+            asm volatile("" : "+v"(acc));         // keeps the sum here (not sunk behind the reads)
+            SDP_READS_FIRST(12, 16);
         }
     }
+    const double ipi = w.ip[ia], ipj = w.ip[j];
+    scale = ((k0 || k1) ? ipi : 1.0) * (k0 ? ipj : 1.0);
+    lf = acc;
     slot = k0 ? i * LD + j : k1 ? -1 - ia : k2 ? -1 - q : INT_MIN;
-    return k0 ? bh : 0.0;
 }
 
-__device__ __forceinline__ void sdp_item_store(const SdpWork w, int slot, double val) {
-    if (slot >= 0) w.H[slot] = val;
-    else if (slot != INT_MIN) w.ci[-1 - slot] = val;
+__device__ __forceinline__ void sdp_item_store(const SdpWork w, int slot, double qf, double lf, double scale) {
+    const double vq = 0.5 * qf * scale * scale, vl = lf * scale;
+    if (slot >= 0) w.H[slot] = vq + vl;
+    else if (slot != INT_MIN) w.ci[-1 - slot] = (slot == -1 - w.q) ? vq + vl : vl - vq;
 }
 
-// PAIR: two items per walk over K (twice the z registers).
-template <int T, int Q, bool EXACT, bool PAIR>
+template <int Q, bool EXACT, bool PAIR>
 __device__ __noinline__ void sdp_hess_items(const SdpWork w) {
+    constexpr int T = 64;
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
@@ -676,32 +748,26 @@ __device__ __noinline__ void sdp_hess_items(const SdpWork w) {
         for (int e0 = tid; e0 < nitems; e0 += 2 * T) {
             double z0[Q], z1[Q];
             int s0, s1;
-            const double b0 = sdp_item_z<Q, EXACT>(w, e0, npair, z0, s0);
-            const double b1 = sdp_item_z<Q, EXACT>(w, e0 + T, npair, z1, s1);
-            double r0, r1;
-            sdp_quadform2<Q, EXACT>(z0, z1, w.Kt, LD, q, r0, r1);
-            sdp_item_store(w, s0, 0.5 * r0 + b0);
-            sdp_item_store(w, s1, 0.5 * r1 + b1);
+            double l0, l1, c0, c1, r0, r1;
+            sdp_item_z<Q, EXACT>(w, LD, e0, npair, z0, l0, c0, s0);
+            sdp_item_z<Q, EXACT>(w, LD, e0 + T, npair, z1, l1, c1, s1);
+            sdp_quadform2<Q, EXACT>(z0, z1, w, LD, q, r0, r1);
+            sdp_item_store(w, s0, r0, l0, c0);
+            sdp_item_store(w, s1, r1, l1, c1);
         }
     } else {
         for (int e0 = tid; e0 < nitems; e0 += T) {
             double z0[Q];
             int s0;
-            const double b0 = sdp_item_z<Q, EXACT>(w, e0, npair, z0, s0);
-            sdp_item_store(w, s0, 0.5 * sdp_quadform1<Q, EXACT>(z0, w.Kt, LD, q) + b0);
+            double l0, c0;
+            sdp_item_z<Q, EXACT>(w, LD, e0, npair, z0, l0, c0, s0);
+            sdp_item_store(w, s0, sdp_quadform1<Q, EXACT>(z0, w, LD, q), l0, c0);
         }
     }
 }
 
-template <int T, int Q>
-__device__ __forceinline__ void sdp_hess_items_q(const SdpWork w) {
-    if (w.q == Q) sdp_hess_items<T, Q, true, (Q <= 20)>(w);
-    else sdp_hess_items<T, Q, false, (Q <= 20)>(w);
-}
-
-// Cholesky A = L L^T of the lower triangle in w.H and the solve A step = grad inside one wave:
-// lane i keeps row i in registers, pivots and multipliers travel by shuffles.  L is written back
-// to w.H (lower) for later solves.  Returns 1 if A is not numerically positive definite.
+// Cholesky of A (lower triangle of w.H) and the solve A step = grad inside one wave.  L is
+// written back to w.H (lower) for later solves.  Returns 1 if A is not numerically PD.
 template <int Q, bool EXACT>
 __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
     const int lane = threadIdx.x;
@@ -715,25 +781,8 @@ __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
         else a[k] = 0.0;
     }
     if (EXACT) SDP_READS_FIRST(Q, 4 * Q);
-    double dinv = 0.0;
-    int fail = 0;
-#pragma unroll
-    for (int k = 0; k < Q; ++k) {
-        if (EXACT || k < q) {
-            const double akk = sdp_lane_bcast(a[k], k);
-            if (!(akk > 0.0)) fail = 1;              // identical in every lane; NaNs flow on
-            const double rinv = sdp_rsq(akk);
-            const double lik = (lane >= k) ? a[k] * rinv : 0.0;
-            a[k] = lik;
-            if (lane == k) dinv = rinv;
-#pragma unroll
-            for (int j = k + 1; j < Q; ++j) {
-                if (EXACT || j < q) { const double ljk = sdp_lane_bcast(lik, j); a[j] -= lik * ljk; }
-            }
-            if (EXACT) __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (fail) return 1;
+    double dinv;
+    if (sdp_chol_rows<Q, EXACT>(a, dinv, q, lane)) return 1;
     if (act) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) if ((EXACT || k < q) && k <= lane) w.H[row * LD + k] = a[k];
@@ -765,137 +814,63 @@ __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
     return 0;
 }
 
-template <int Q>
-__device__ __forceinline__ int sdp_chol_solve_q(const SdpWork w) {
-    return (w.q == Q) ? sdp_chol_solve_reg<Q, true>(w) : sdp_chol_solve_reg<Q, false>(w);
-}
-
-// generic-size fallback of the same items (LDS variant)
-template <int T>
-__device__ void sdp_hess_items_lds(const SdpWork w) {
+// w.step = (-hess g)^-1 grad g at the state left by sdp_eval_reg (which stays intact: U in w.X).
+// Overwrites w.H (K' above, the factor of A in and below the diagonal), w.ci, w.step.
+template <int Q, bool EXACT>
+__device__ int sdp_newton_dir_reg(const SdpWork w) {
+    constexpr int T = 64;
     const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
-    const lds_f64* Wv = w.X;
-    const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
-    for (int e = tid; e < nitems; e += T) {
-        int i = 0, j = 0, kind = 2;
-        if (e < npair) {
-            i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            j = e - i * (i + 1) / 2;
-            kind = 0;
-        } else if (e < npair + q) { i = e - npair; kind = 1; }
-        double tot = 0.0, bh = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double ma = w.sq[a] * w.rp[a];
-            const double za = kind == 0 ? Wv[i * LD + a] * Wv[j * LD + a] : kind == 1 ? Wv[i * LD + a] * ma : ma * ma;
-            double inner = 0.5 * w.Kt[a * LD + a] * za;
-#pragma unroll 4
-            for (int b = 0; b < a; ++b) {
-                const double mb = w.sq[b] * w.rp[b];
-                const double zb = kind == 0 ? Wv[i * LD + b] * Wv[j * LD + b] : kind == 1 ? Wv[i * LD + b] * mb : mb * mb;
-                inner += w.Kt[a * LD + b] * zb;
-            }
-            tot += za * inner;
-            if (kind == 0) bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
-        }
-        if (kind == 0) w.H[i * LD + j] = tot + bh;
-        else if (kind == 1) w.ci[i] = tot;
-        else w.ci[q] = tot;
-    }
-}
-
-template <int T>
-__device__ int sdp_newton_dir(const SdpWork w) {
-    const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
-    lds_f64* Wv = w.X;      // the decomposition is finished: X is free for reuse
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     __syncthreads();
     SDP_TIC(t_items);
     for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, a = e - i * q;
-        const double m = w.sq[a] * w.rp[a];
-        Wv[i * LD + a] = w.R[i * LD + a] * w.sq[a] - m;
-        w.Kt[i * LD + a] = sdp_rcp(w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
-    }
-    if (tid < q) w.tv[tid] = w.sq[tid] * w.rp[tid];        // m
-    __syncthreads();
-    // raw items: H[i][j] = Q_ij/2 + (B/2)_ij, ci[i] = c_i/2, ci[q] = c_0/2
-    if constexpr (T == 64) {
-        if (q <= 8) sdp_hess_items_q<T, 8>(w);
-        else if (q <= 16) sdp_hess_items_q<T, 16>(w);
-        else if (q <= 20) sdp_hess_items_q<T, 20>(w);
-        else sdp_hess_items_q<T, 32>(w);
-    } else {
-        sdp_hess_items_lds<T>(w);
+        const int a = EXACT ? e / Q : e / q, b = e - a * q;
+        if (b < a) {
+            const double sa = w.sq[a], sb = w.sq[b];
+            w.H[b * LD + a] = sa * sb * sdp_rcp(sa + sb);
+        }
     }
     __syncthreads();
-    const double c0 = w.ci[q];
+    sdp_hess_items<Q, EXACT, (Q <= 20)>(w);
+    __syncthreads();
+    const double e0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
     for (int e = tid; e < npair; e += T) {
-        int i = (int)((sqrtf(8.f * (float)e + 1.f) - 1.f) * 0.5f);
-        while ((i + 1) * (i + 2) / 2 <= e) ++i;
-        while (i * (i + 1) / 2 > e) --i;
-        const int j = e - i * (i + 1) / 2;
-        w.H[i * LD + j] += c0 - w.ci[i] - w.ci[j];
+        int i, j;
+        sdp_tri_index(e, i, j);
+        w.H[i * LD + j] += e0 + w.ci[i] + w.ci[j];
     }
     __syncthreads();
     SDP_TOC(4, t_items);
     SDP_TIC(t_chol);
-    // Cholesky of A (lower) and solve A step = grad
-    if constexpr (T == 64) {
-        int f;
-        if (q <= 8) f = sdp_chol_solve_q<8>(w);
-        else if (q <= 16) f = sdp_chol_solve_q<16>(w);
-        else if (q <= 20) f = sdp_chol_solve_q<20>(w);
-        else f = sdp_chol_solve_q<32>(w);
-        SDP_TOC(5, t_chol);
-        return f;
-    }
-    int fail = 0;
-    for (int k = 0; k < q; ++k) {
-        const double akk = w.H[k * LD + k];
-        if (!(akk > 0.0)) { fail = 1; break; }     // identical in every thread
-        const double piv = sqrt(akk);
-        __syncthreads();
-        if (tid == 0) w.H[k * LD + k] = piv;
-        for (int i = k + 1 + tid; i < q; i += T) w.H[i * LD + k] /= piv;
-        __syncthreads();
-        const int rem = q - k - 1;
-        for (int e = tid; e < rem * rem; e += T) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) w.H[i * LD + j] -= w.H[i * LD + k] * w.H[j * LD + k];
-        }
-        __syncthreads();
-    }
-    if (fail) return 1;
-    SDP_TIC(t_tri);
-    if (tid < q) w.step[tid] = w.grad[tid];
-    __syncthreads();
-    for (int k = 0; k < q; ++k) {          // forward: L y = grad
-        const double yk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = yk;
-        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
-        __syncthreads();
-    }
-    for (int k = q - 1; k >= 0; --k) {     // backward: L^T x = y
-        const double xk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = xk;
-        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
-        __syncthreads();
-    }
-    SDP_TOC(6, t_tri);
-    return 0;
+    const int f = sdp_chol_solve_reg<Q, EXACT>(w);
+    SDP_TOC(5, t_chol);
+    return f;
+}
+
+// ---- dispatch between the two paths: Q > 0 register path (T == 64), Q == 0 LDS path ------------
+template <int T, int Q>
+__device__ __forceinline__ int sdp_factor(const SdpWork w) {
+    if constexpr (Q > 0) return (w.q == Q) ? sdp_factor_reg<Q, true>(w) : sdp_factor_reg<Q, false>(w);
+    else return 0;                       // the LDS path keeps S itself
+}
+template <int T, int Q>
+__device__ __forceinline__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
+    if constexpr (Q > 0)
+        return (w.q == Q) ? sdp_eval_reg<Q, true>(w, pt, sweeps, warm) : sdp_eval_reg<Q, false>(w, pt, sweeps, warm);
+    else return sdp_eval_lds<T>(w, pt, sweeps);
+}
+template <int T, int Q>
+__device__ __forceinline__ int sdp_newton_dir(const SdpWork w) {
+    if constexpr (Q > 0) return (w.q == Q) ? sdp_newton_dir_reg<Q, true>(w) : sdp_newton_dir_reg<Q, false>(w);
+    else return sdp_newton_dir_lds<T>(w);
 }
 
 // ================================================================================================
 // Full solve.  On entry w.S (symmetric) and w.dl are set.  On exit w.p holds the optimum and the
-// state (X = U, sv, sq, R, rp, s) belongs to it.  Returns status; *g_out = max g.
+// state (U in w.X, sv, sq, rp, ip, s) belongs to it.  Returns status; *g_out = max g.
 // ================================================================================================
-template <int T>
+template <int T, int Q>
 __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
@@ -915,12 +890,12 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
 #ifdef OEI_SDP_TIMING
     if (tid == 0) { for (int i = 0; i < 8; ++i) w.scal[i] = 0.0; }
 #endif
-    if (sdp_factor<T>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
-    double g = sdp_eval<T>(w, w.p, sweeps, false);
+    if (sdp_factor<T, Q>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
+    double g = sdp_eval<T, Q>(w, w.p, sweeps, false);
     if (!(g > -INFINITY)) { *g_out = g; *iters_out = 0; return 2; }
     for (it = 1; it <= SDP_MAX_NEWTON; ++it) {
         SDP_TIC(t_dir);
-        const int dir_fail = sdp_newton_dir<T>(w);
+        const int dir_fail = sdp_newton_dir<T, Q>(w);
         SDP_TOC(3, t_dir);
         if (dir_fail) { status = 2; break; }
         double rel = 0.0, ssum = 0.0, dec = 0.0, psum = 0.0;
@@ -940,7 +915,7 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
             __syncthreads();
             if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
             __syncthreads();
-            gn = sdp_eval<T>(w, w.pn, sweeps, true);
+            gn = sdp_eval<T, Q>(w, w.pn, sweeps, true);
             if (gn >= g + 1e-4 * t * dec - slack) break;
             t *= 0.5; full = false;
         }
@@ -958,7 +933,7 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
 
 // ---- outputs from the final state ---------------------------------------------------------------
 // Writes N = B^-1 into w.H and c into w.ci, (N c) into w.tv; returns nu = c^T N c.
-// Needs w.X = U, w.sq, w.R, w.rp of the optimum; `mu` in LDS.
+// Needs w.X = U, w.sq, w.ip, w.rp of the optimum; `mu` in LDS.
 template <int T>
 __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
     const int tid = threadIdx.x;
@@ -967,7 +942,7 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
     __syncthreads();
     if (tid < q) {     // c = mu + B p / 2 = mu + R (sq * rp)
         double acc = 0.0;
-        for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * w.rp[a];
+        for (int a = 0; a < q; ++a) acc += sdp_R(w, tid, a) * w.sq[a] * w.rp[a];
         w.ci[tid] = mu[tid] + acc;
     }
     for (int e = tid; e < q * q; e += T) {
@@ -990,3 +965,11 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
     for (int i = 0; i < q; ++i) nu += w.ci[i] * w.tv[i];
     return nu;
 }
+
+// Host-side choice of the kernel instance for a given q: CALL(T, Q) with Q = 0 for the LDS path.
+#define SDP_DISPATCH_Q(q, CALL) do { \
+        if ((q) <= 8) { CALL(64, 8); } else if ((q) <= 16) { CALL(64, 16); } \
+        else if ((q) <= 20) { CALL(64, 20); } else if ((q) <= 32) { CALL(64, 32); } \
+        else { CALL(256, 0); } } while (0)
+// waves per SIMD the register budget is tuned for (launch bound of the solver kernels)
+#define SDP_MIN_WAVES(Q) ((Q) == 0 ? 1 : (Q) <= 20 ? 3 : 2)

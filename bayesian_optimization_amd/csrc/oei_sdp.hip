@@ -2,16 +2,16 @@
 // Replaces sdp.sdp of the reference (sdp.py:11-67) for B independent problems at once.
 #include "oei_sdp.cuh"
 
-template <int T>
-__global__ __launch_bounds__(T, 2) void k_sdp_omega(int q, const double* __restrict__ omega,
+template <int T, int Q>
+__global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_sdp_omega(int q, const double* __restrict__ omega,
                                                  const double* __restrict__ fmin,
                                                  double* __restrict__ value, double* __restrict__ M,
                                                  double* __restrict__ Y, int* __restrict__ status,
                                                  int* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
-    sdp_carve(w, sm, q);
-    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q);          // [q]
+    sdp_carve(w, sm, q, Q == 0);
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, Q == 0);  // [q]
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int k_ = q + 1, LD = w.LD;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(T, 2) void k_sdp_omega(int q, const double* __restr
     bad = __syncthreads_or(bad);
     double g = 0.0;
     int it = 0, st = 2;
-    if (!bad) st = sdp_solve<T>(w, &g, &it);
+    if (!bad) st = sdp_solve<T, Q>(w, &g, &it);
     double* Mo = M + (size_t)b * k_ * k_;
     if (st == 2) {        // no usable state: report NaN like a failed solve, never stale memory
         for (int e = tid; e < k_ * k_; e += T) Mo[e] = NAN;
@@ -52,14 +52,15 @@ __global__ __launch_bounds__(T, 2) void k_sdp_omega(int q, const double* __restr
         Mo[e] = v;
     }
     if (Y) {
-        // y_0 = sqrt(w0 p0) [c;1];  y_i = sqrt(w0 p_i) [c - B e_i/2; 1],  B/2 = R sq R^T (in w.V after
-        // the Newton direction of the last iteration is NOT guaranteed) -> recompute B/2 into w.Kt.
+        // y_0 = sqrt(w0 p0) [c;1];  y_i = sqrt(w0 p_i) [c - B e_i/2; 1],  B/2 = R sq R^T into w.S
+        // (the factor of S is no longer needed)
         __syncthreads();
+        lds_f64* Bh = w.S;
         for (int e = tid; e < q * q; e += T) {
             const int i = e / q, j = e - i * q;
             double acc = 0.0;
-            for (int a = 0; a < q; ++a) acc += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
-            w.Kt[i * LD + j] = acc;
+            for (int a = 0; a < q; ++a) acc += sdp_R(w, i, a) * sdp_R(w, j, a) * w.sq[a];
+            Bh[i * LD + j] = acc;
         }
         __syncthreads();
         double psum = 0.0;
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(T, 2) void k_sdp_omega(int q, const double* __restr
             const int blk = e / (k_ * k_), rem = e - blk * k_ * k_;
             const int i = rem / k_, j = rem - i * k_;
             const double wgt = w0 * (blk == 0 ? (1.0 - psum) : w.p[blk - 1]);
-            double yi = (i < q) ? w.ci[i] - (blk ? w.Kt[i * LD + (blk - 1)] : 0.0) : 1.0;
-            double yj = (j < q) ? w.ci[j] - (blk ? w.Kt[j * LD + (blk - 1)] : 0.0) : 1.0;
+            double yi = (i < q) ? w.ci[i] - (blk ? Bh[i * LD + (blk - 1)] : 0.0) : 1.0;
+            double yj = (j < q) ? w.ci[j] - (blk ? Bh[j * LD + (blk - 1)] : 0.0) : 1.0;
             Yo[e] = wgt * yi * yj;
         }
     }
@@ -88,15 +89,13 @@ extern "C" int oei_sdp_batched(int B, int k_, const double* omega, const double*
     if (B == 0) return OEI_OK;
     if (!omega || !fmin || !value || !M || !status) { oei_set_error("sdp_batched: null pointer"); return OEI_ERR_ARG; }
     const int q = k_ - 1;
-    const size_t lds = (sdp_work_doubles(q) + q + 2) * sizeof(double);
     hipStream_t st = (hipStream_t)stream;
-    if (q <= 32) {
-        if (lds > 48 * 1024) OEI_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdp_omega<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_sdp_omega<64>, dim3(B), dim3(64), lds, st, q, omega, fmin, value, M, Y, status, iters);
-    } else {
-        if (lds > 48 * 1024) OEI_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdp_omega<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_sdp_omega<256>, dim3(B), dim3(256), lds, st, q, omega, fmin, value, M, Y, status, iters);
-    }
+#define LAUNCH_SDP(T_, Q_) do { \
+        const size_t lds = (sdp_work_doubles(q, (Q_) == 0) + q + 2) * sizeof(double); \
+        if (lds > 48 * 1024) OEI_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdp_omega<T_, Q_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_sdp_omega<T_, Q_>), dim3(B), dim3(T_), lds, st, q, omega, fmin, value, M, Y, status, iters); } while (0)
+    SDP_DISPATCH_Q(q, LAUNCH_SDP);
+#undef LAUNCH_SDP
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

@@ -32,9 +32,10 @@ __device__ inline void sens_carve(SensVec& sv, lds_f64* base, int q) {
     sv.w1 = base + 6 * VL;   sv.w2 = base + 7 * VL;  sv.c = base + 8 * VL;
 }
 
-// After sdp_eval at the optimum w.p: store U in w.S, factor -hess g in w.H (lower Cholesky),
-// c in sv.c, t1 = sq o rp.  Leaves w.X, w.V, w.Kt free.  Returns non-zero on breakdown.
-template <int T>
+// After sdp_eval at the optimum w.p (full LDS layout): store U in w.S, R in w.R, factor -hess g in
+// w.H (lower Cholesky), c in sv.c, t1 = sq o rp.  Leaves w.X, w.V, w.Kt free.  Returns non-zero
+// on breakdown.
+template <int T, int Q>
 __device__ int sens_prepare(const SdpWork w, const lds_f64* mu, const SensVec sv) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
@@ -42,9 +43,10 @@ __device__ int sens_prepare(const SdpWork w, const lds_f64* mu, const SensVec sv
     for (int e = tid; e < q * q; e += T) {         // the evaluation left U in w.X
         const int i = e / q, a = e - i * q;
         w.S[i * LD + a] = w.X[i * LD + a];
+        w.R[i * LD + a] = sdp_R(w, i, a);
     }
     __syncthreads();
-    if (sdp_newton_dir<T>(w)) return 1;
+    if (sdp_newton_dir<T, Q>(w)) return 1;
     __syncthreads();
     if (tid < q) {
         double acc = 0.0;
