@@ -162,20 +162,39 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
         const int i = e / q, j = e - i * q;
         M11_out[(size_t)b * q * q + e] = -w.H[i * LD + j];
     }
-    // Z[a, k] = sum_b M11[a, b] A[b, k]   (staging overwrites solver scratch; only w.H = N is live)
-    const int nchunks = npad / CH;
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();
-        for (int e = tid; e < q * CH; e += T) {
-            const int a = e / CH, k = e - a * CH;
-            Ac[a * (CH + 1) + k] = Arows[(size_t)a * a_row_stride + c * CH + k];
+    // Z[a, k] = sum_b M11[a, b] A[b, k] with M11 = -N (w.H)
+    if constexpr (Q > 0) {
+        // lane k keeps column k of the candidate's A rows in registers; N is read as broadcasts
+        for (int col = tid; col < npad; col += T) {
+            double av[Q];
+#pragma unroll
+            for (int bb = 0; bb < Q; ++bb) av[bb] = (bb < q) ? Arows[(size_t)bb * a_row_stride + col] : 0.0;
+#pragma unroll 2
+            for (int a = 0; a < q; ++a) {
+                double s = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < Q; ++bb) {
+                    const double h = w.H[a * LD + bb];      // beyond q: inside the LDS allocation, discarded
+                    s -= ((bb < q) ? h : 0.0) * av[bb];
+                }
+                Zrows[(size_t)a * npad + col] = s;
+            }
         }
-        __syncthreads();
-        for (int e = tid; e < q * CH; e += T) {
-            const int a = e / CH, k = e - a * CH;
-            double s = 0.0;
-            for (int bb = 0; bb < q; ++bb) s -= w.H[a * LD + bb] * Ac[bb * (CH + 1) + k];
-            Zrows[(size_t)a * npad + c * CH + k] = s;
+    } else {
+        const int nchunks = npad / CH;
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();
+            for (int e = tid; e < q * CH; e += T) {
+                const int a = e / CH, k = e - a * CH;
+                Ac[a * (CH + 1) + k] = Arows[(size_t)a * a_row_stride + c * CH + k];
+            }
+            __syncthreads();
+            for (int e = tid; e < q * CH; e += T) {
+                const int a = e / CH, k = e - a * CH;
+                double s = 0.0;
+                for (int bb = 0; bb < q; ++bb) s -= w.H[a * LD + bb] * Ac[bb * (CH + 1) + k];
+                Zrows[(size_t)a * npad + c * CH + k] = s;
+            }
         }
     }
 }
@@ -184,7 +203,10 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
 // For each chunk of CH training points: ck[a][k] = (p_a alpha_k - 2 W[a,k]) * 2 var kappa'(t_ak),
 // then G[a][l] += sum_k ck[a][k] X[k][l] and G[a][d] += sum_k ck[a][k]; finally
 // grad[a][l] = (x_al G[a][d] - G[a][l]) / ls_l^2 + self terms.  Also raises the `project` flag.
-template <int T>
+// Thread t owns training point k = t mod CH of the chunk (coordinates in registers when the
+// dimension D is a compile-time constant, D = 0: any dimension, read back from LDS) and walks the
+// candidate's points a = t / CH, t / CH + T / CH, ...; W rows are read coalesced along k.
+template <int T, int D>
 __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int q,
                                             const double* __restrict__ Xtrain,
                                             const double* __restrict__ alpha,
@@ -194,13 +216,13 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
                                             const double* __restrict__ M11_in,
                                             double* __restrict__ grad, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int d = kp.d, dp = d + 1, dl = (d + 1) | 1;
-    double* xq = sm;                         // [q][d]
-    double* M11 = xq + q * d;                // [q][q]
-    double* pv = M11 + q * q;                // [q]
-    double* ck = pv + q;                     // [q][CH+1]
-    double* Xc = ck + q * (CH + 1);          // [CH][dl]   (column d holds 1)
-    double* Gs = Xc + CH * dl;               // [q][q]     2 var kappa'(t_ab)
+    const int d = D > 0 ? D : kp.d, dp = d + 1, dl = (d + 1) | 1;
+    lds_f64* xq = (lds_f64*)sm;               // [q][d]
+    lds_f64* M11 = xq + q * d;                // [q][q]
+    lds_f64* pv = M11 + q * q;                // [q]
+    lds_f64* ck = pv + q;                     // [q][CH+1]
+    lds_f64* Xc = ck + q * (CH + 1);          // [CH][dl]   (column d holds 1)
+    lds_f64* Gs = Xc + CH * dl;               // [q][q]     2 var kappa'(t_ab)
     const int tid = threadIdx.x, b = blockIdx.x;
     for (int e = tid; e < q * d; e += T) xq[e] = Xq[(size_t)b * q * d + e];
     for (int e = tid; e < q * q; e += T) M11[e] = M11_in[(size_t)b * q * q + e];
@@ -213,30 +235,52 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
     int flag = 0;
     const double* Wrows = Wm + (size_t)b * q * npad;
     const int nchunks = (n + CH - 1) / CH;
+    const int k = tid & (CH - 1), ag = tid / CH;
+    constexpr int NA = T / CH;
+    const double var2 = 2.0 * kp.variance;
     for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();
-        for (int e = tid; e < CH * dp; e += T) {
-            const int k = e / dp, l = e - k * dp, kg = c * CH + k;
-            Xc[k * dl + l] = (l == d) ? 1.0 : ((kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0);
+        const int kg = c * CH + k;
+        const bool valid = kg < n;
+        double xk[D > 0 ? D : 1];
+        if constexpr (D > 0) {
+#pragma unroll
+            for (int l = 0; l < D; ++l) xk[l] = valid ? Xtrain[(size_t)kg * D + l] : 0.0;
         }
-        __syncthreads();
-        for (int e = tid; e < q * CH; e += T) {
-            const int a = e / CH, k = e - a * CH, kg = c * CH + k;
+        const double al = valid ? alpha[kg] : 0.0;
+        __syncthreads();                     // the previous chunk's contraction is done
+        if (ag == 0) {
+            if constexpr (D > 0) {
+#pragma unroll
+                for (int l = 0; l < D; ++l) Xc[k * dl + l] = xk[l];
+            } else {
+                for (int l = 0; l < d; ++l) Xc[k * dl + l] = valid ? Xtrain[(size_t)kg * d + l] : 0.0;
+            }
+            Xc[k * dl + d] = 1.0;
+        }
+        if constexpr (D == 0) __syncthreads();
+#pragma unroll 2
+        for (int a = ag; a < q; a += NA) {
+            const double wv = valid ? Wrows[(size_t)a * npad + kg] : 0.0;
             double t = 0.0;
             bool close = true;
-            for (int l = 0; l < d; ++l) {
-                const double df = xq[a * d + l] - Xc[k * dl + l];
-                t += df * df * kp.inv_ls2[l];
-                close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
+            if constexpr (D > 0) {
+#pragma unroll
+                for (int l = 0; l < D; ++l) {
+                    const double df = xq[a * D + l] - xk[l];
+                    t += df * df * kp.inv_ls2[l];
+                    close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
+                }
+            } else {
+                for (int l = 0; l < d; ++l) {
+                    const double df = xq[a * d + l] - Xc[k * dl + l];
+                    t += df * df * kp.inv_ls2[l];
+                    close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
+                }
             }
             double k0, k1, k2;
             kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
-            double val = 0.0;
-            if (kg < n) {
-                val = (pv[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg]) * 2.0 * kp.variance * k1;
-                if (close) flag = 1;
-            }
-            ck[a * (CH + 1) + k] = val;
+            ck[a * (CH + 1) + k] = valid ? (pv[a] * al - 2.0 * wv) * var2 * k1 : 0.0;
+            if (valid && close) flag = 1;
         }
         __syncthreads();
 #pragma unroll
@@ -244,12 +288,15 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
             if (u * T >= nitems) break;                  // uniform; idle lanes redo item 0
             const int e = (tid + u * T < nitems) ? tid + u * T : 0;
             const int a = e / dp, l = e - a * dp;
-            const double* ca = ck + a * (CH + 1);
-            const double* xl = Xc + l;
-            double s = 0.0;
+            const lds_f64* ca = ck + a * (CH + 1);
+            const lds_f64* xl = Xc + l;
+            double s0 = 0.0, s1 = 0.0;
 #pragma unroll 4
-            for (int k = 0; k < CH; ++k) s += ca[k] * xl[k * dl];
-            acc[u] += s;
+            for (int kk = 0; kk < CH; kk += 2) {
+                s0 += ca[kk] * xl[kk * dl];
+                s1 += ca[kk + 1] * xl[(kk + 1) * dl];
+            }
+            acc[u] += s0 + s1;
         }
     }
     // self-covariance derivative factors and mutual-duplicate test (oei.py:190)
@@ -268,7 +315,7 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
         if (a != bb && same) flag = 1;
     }
     __syncthreads();
-    double* Gacc = ck;      // reuse: [q][dp]
+    lds_f64* Gacc = ck;     // reuse: [q][dp]
 #pragma unroll
     for (int u = 0; u < ITEMS_MAX; ++u) {
         const int e = tid + u * T;
@@ -458,11 +505,16 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
     if (q <= 32) {
-        if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
-        hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+        if (d == 6) {
+            if ((rc = set_lds(k_grad<64, 6>, ldsg))) return rc;
+            hipLaunchKernelGGL((k_grad<64, 6>), dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+        } else {
+            if ((rc = set_lds(k_grad<64, 0>, ldsg))) return rc;
+            hipLaunchKernelGGL((k_grad<64, 0>), dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+        }
     } else {
-        if ((rc = set_lds(k_grad<256>, ldsg))) return rc;
-        hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+        if ((rc = set_lds(k_grad<256, 0>, ldsg))) return rc;
+        hipLaunchKernelGGL((k_grad<256, 0>), dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
     }
     OEI_HIP_CHECK(hipGetLastError());
     if (prof) { OEI_HIP_CHECK(hipEventRecord(m->ev[5], st)); m->ev_valid = 1; }

@@ -932,7 +932,7 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
 }
 
 // ---- outputs from the final state ---------------------------------------------------------------
-// Writes N = B^-1 into w.H and c into w.ci, (N c) into w.tv; returns nu = c^T N c.
+// Writes N = B^-1 into w.H and c into w.ci, (N c) into w.tv (w.step is scratch); returns c^T N c.
 // Needs w.X = U, w.sq, w.ip, w.rp of the optimum; `mu` in LDS.
 template <int T>
 __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
@@ -944,15 +944,17 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
         double acc = 0.0;
         for (int a = 0; a < q; ++a) acc += sdp_R(w, tid, a) * w.sq[a] * w.rp[a];
         w.ci[tid] = mu[tid] + acc;
+        w.step[tid] = 0.5 / w.sq[tid];
     }
+    __syncthreads();
     for (int e = tid; e < q * q; e += T) {
         const int i = e / q, j = e - i * q;
         if (j > i) continue;
         double acc = 0.0;
 #pragma unroll 4
-        for (int a = 0; a < q; ++a) acc += U[i * LD + a] * U[j * LD + a] / w.sq[a];
-        w.H[i * LD + j] = 0.5 * acc;
-        w.H[j * LD + i] = 0.5 * acc;
+        for (int a = 0; a < q; ++a) acc += U[i * LD + a] * U[j * LD + a] * w.step[a];
+        w.H[i * LD + j] = acc;
+        w.H[j * LD + i] = acc;
     }
     __syncthreads();
     if (tid < q) {
