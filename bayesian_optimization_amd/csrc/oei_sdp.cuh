@@ -45,6 +45,11 @@
 #define SDP_JACOBI_TOL 1e-15
 #define SDP_STEP_TOL 1e-7
 #define SDP_JACOBI_FINAL 1e-7
+// evaluations that only steer the Newton iteration (every one but the last) stop earlier
+#define SDP_JACOBI_TOL_LOOSE 1e-11
+#define SDP_JACOBI_FINAL_LOOSE 1e-5
+#define SDP_EVAL_WARM 1
+#define SDP_EVAL_LOOSE 2
 
 // Inside one scheduling region: issue the LDS reads (up to nr) back to back, then the arithmetic,
 // and close the region.  Without this the register-pressure heuristic of the scheduler tends to
@@ -405,7 +410,7 @@ __device__ int sdp_newton_dir_lds(const SdpWork w) {
 // norms are carried along (alpha_i -= t gamma, alpha_j += t gamma) and recomputed once per sweep.
 // Q is the padded size (even); columns >= q are zero and never rotate.  Returns the sweep count.
 template <int Q>
-__device__ int sdp_jacobi_reg(double (&g)[Q]) {
+__device__ int sdp_jacobi_reg(double (&g)[Q], double tol2, double fin2) {
     const int lane = threadIdx.x & 63;
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
@@ -433,7 +438,7 @@ __device__ int sdp_jacobi_reg(double (&g)[Q]) {
             double c = 1.0, sg = 0.0;
             const double g2 = gamma * gamma, aa = alpha * beta;
             const bool rot = (lane < Q) && (partner != lane) &&
-                             (g2 > SDP_JACOBI_TOL * SDP_JACOBI_TOL * aa);
+                             (g2 > tol2 * aa);
             if (rot) {
                 // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = alpha_j - alpha_i  (i < j)
                 const double d = low ? beta - alpha : alpha - beta;
@@ -448,7 +453,7 @@ __device__ int sdp_jacobi_reg(double (&g)[Q]) {
             }
             // the iteration converges quadratically: once every rotation of a sweep had
             // |gamma| <= 1e-7 sqrt(alpha beta), what is left afterwards is below the tolerance
-            rotated |= rot && (g2 > SDP_JACOBI_FINAL * SDP_JACOBI_FINAL * aa);
+            rotated |= rot && (g2 > fin2 * aa);
 #pragma unroll
             for (int k = 0; k < Q; ++k) g[k] = c * g[k] + sg * pg[k];
         }
@@ -515,7 +520,7 @@ __device__ __noinline__ int sdp_factor_reg(const SdpWork w) {
 // G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
 // Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
 template <int Q, bool EXACT>
-__device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
+__device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     SDP_TIC(t_setup);
@@ -562,7 +567,7 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
         }
         if (EXACT) SDP_READS_FIRST(2 * Q, 4 * Q);
     }
-    if (warm) {
+    if (mode & SDP_EVAL_WARM) {
         lds_f64* GT = w.H;
         if (act) {
 #pragma unroll
@@ -583,7 +588,12 @@ __device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, 
     }
     SDP_TOC(0, t_setup);
     SDP_TIC(t_jac);
-    sweeps += sdp_jacobi_reg<Q>(g);
+    {
+        const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
+        const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
+        const double fin = loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
+        sweeps += sdp_jacobi_reg<Q>(g, tol * tol, fin * fin);
+    }
     SDP_TOC(1, t_jac);
     SDP_TIC(t_rest);
     // singular values = column norms; U = Lc^-T (G V) by back substitution, one column per lane
@@ -855,9 +865,9 @@ __device__ __forceinline__ int sdp_factor(const SdpWork w) {
     else return 0;                       // the LDS path keeps S itself
 }
 template <int T, int Q>
-__device__ __forceinline__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, bool warm) {
+__device__ __forceinline__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     if constexpr (Q > 0)
-        return (w.q == Q) ? sdp_eval_reg<Q, true>(w, pt, sweeps, warm) : sdp_eval_reg<Q, false>(w, pt, sweeps, warm);
+        return (w.q == Q) ? sdp_eval_reg<Q, true>(w, pt, sweeps, mode) : sdp_eval_reg<Q, false>(w, pt, sweeps, mode);
     else return sdp_eval_lds<T>(w, pt, sweeps);
 }
 template <int T, int Q>
@@ -891,7 +901,7 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
     if (tid == 0) { for (int i = 0; i < 8; ++i) w.scal[i] = 0.0; }
 #endif
     if (sdp_factor<T, Q>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
-    double g = sdp_eval<T, Q>(w, w.p, sweeps, false);
+    double g = sdp_eval<T, Q>(w, w.p, sweeps, SDP_EVAL_LOOSE);
     if (!(g > -INFINITY)) { *g_out = g; *iters_out = 0; return 2; }
     for (it = 1; it <= SDP_MAX_NEWTON; ++it) {
         SDP_TIC(t_dir);
@@ -915,7 +925,7 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
             __syncthreads();
             if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
             __syncthreads();
-            gn = sdp_eval<T, Q>(w, w.pn, sweeps, true);
+            gn = sdp_eval<T, Q>(w, w.pn, sweeps, SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
             if (gn >= g + 1e-4 * t * dec - slack) break;
             t *= 0.5; full = false;
         }
