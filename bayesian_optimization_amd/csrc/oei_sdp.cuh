@@ -418,22 +418,23 @@ __device__ int sdp_jacobi_reg(double (&g)[Q], double tol2, double fin2) {
         double alpha = 0.0;
 #pragma unroll
         for (int k = 0; k < Q; ++k) alpha += g[k] * g[k];
+        // round-robin pairing: lanes < Q-1 meet (2r - lane) mod (Q-1), the fixed point of that map
+        // meets lane Q-1; `base` follows (2r - lane) mod (Q-1) incrementally
+        int base = (lane < Q - 1) ? ((Q - 1 - lane) % (Q - 1)) : 0;
         for (int r = 0; r < Q - 1; ++r) {
             int partner = lane;
-            if (lane < Q - 1) {
-                partner = (2 * r - lane) % (Q - 1);
-                if (partner < 0) partner += Q - 1;
-                if (partner == lane) partner = Q - 1;
-            } else if (lane == Q - 1) {
-                partner = r;
-            }
+            if (lane < Q - 1) partner = (base == lane) ? Q - 1 : base;
+            else if (lane == Q - 1) partner = r;
+            base += 2;
+            if (base >= Q - 1) base -= Q - 1;
             double pg[Q];
-            double gamma = 0.0;
 #pragma unroll
             for (int k = 0; k < Q; ++k) pg[k] = __shfl(g[k], partner, 64);
             const double beta = __shfl(alpha, partner, 64);
+            double gm0 = 0.0, gm1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) gamma += g[k] * pg[k];
+            for (int k = 0; k < Q; k += 2) { gm0 += g[k] * pg[k]; gm1 += g[k + 1] * pg[k + 1]; }
+            const double gamma = gm0 + gm1;
             const bool low = lane < partner;
             double c = 1.0, sg = 0.0;
             const double g2 = gamma * gamma, aa = alpha * beta;
