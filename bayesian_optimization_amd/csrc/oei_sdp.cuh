@@ -492,7 +492,7 @@ __device__ __forceinline__ int sdp_chol_rows(double (&a)[Q], double& dinv, int q
 // In-place Cholesky S = Lc Lc^T of w.S (lower; the strict upper part is zeroed), reciprocal
 // diagonal in w.rc.  Returns non-zero if S is not PD.
 template <int Q, bool EXACT>
-__device__ __noinline__ int sdp_factor_reg(const SdpWork w) {
+__device__ __forceinline__ int sdp_factor_reg(const SdpWork w) {
     const int lane = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const bool act = lane < q;
@@ -521,7 +521,7 @@ __device__ __noinline__ int sdp_factor_reg(const SdpWork w) {
 // G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
 // Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
 template <int Q, bool EXACT>
-__device__ __noinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+__device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     SDP_TIC(t_setup);
@@ -750,7 +750,7 @@ __device__ __forceinline__ void sdp_item_store(const SdpWork w, int slot, double
 }
 
 template <int Q, bool EXACT, bool PAIR>
-__device__ __noinline__ void sdp_hess_items(const SdpWork w) {
+__device__ __forceinline__ void sdp_hess_items(const SdpWork w) {
     constexpr int T = 64;
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
@@ -780,7 +780,7 @@ __device__ __noinline__ void sdp_hess_items(const SdpWork w) {
 // Cholesky of A (lower triangle of w.H) and the solve A step = grad inside one wave.  L is
 // written back to w.H (lower) for later solves.  Returns 1 if A is not numerically PD.
 template <int Q, bool EXACT>
-__device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
+__device__ __forceinline__ int sdp_chol_solve_reg(const SdpWork w) {
     const int lane = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const bool act = lane < q;
@@ -828,7 +828,7 @@ __device__ __noinline__ int sdp_chol_solve_reg(const SdpWork w) {
 // w.step = (-hess g)^-1 grad g at the state left by sdp_eval_reg (which stays intact: U in w.X).
 // Overwrites w.H (K' above, the factor of A in and below the diagonal), w.ci, w.step.
 template <int Q, bool EXACT>
-__device__ int sdp_newton_dir_reg(const SdpWork w) {
+__device__ __forceinline__ int sdp_newton_dir_reg(const SdpWork w) {
     constexpr int T = 64;
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
@@ -860,20 +860,47 @@ __device__ int sdp_newton_dir_reg(const SdpWork w) {
 }
 
 // ---- dispatch between the two paths: Q > 0 register path (T == 64), Q == 0 LDS path ------------
+// Inside the solver the register-path pieces are inlined (one call site each): a real call would
+// save and restore the callee-saved half of a 170-register frame through scratch memory every
+// time.  The kernels that use single pieces (sensitivities) call them out of line instead.
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ int sdp_factor_x(const SdpWork w) {
+    if constexpr (Q > 0) return sdp_factor_reg<Q, EXACT>(w);
+    else return 0;                       // the LDS path keeps S itself
+}
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ double sdp_eval_x(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+    if constexpr (Q > 0) return sdp_eval_reg<Q, EXACT>(w, pt, sweeps, mode);
+    else return sdp_eval_lds<T>(w, pt, sweeps);
+}
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ int sdp_newton_dir_x(const SdpWork w) {
+    if constexpr (Q > 0) return sdp_newton_dir_reg<Q, EXACT>(w);
+    else return sdp_newton_dir_lds<T>(w);
+}
+template <int T, int Q, bool EXACT>
+__device__ __noinline__ int sdp_factor_call(const SdpWork w) { return sdp_factor_x<T, Q, EXACT>(w); }
+template <int T, int Q, bool EXACT>
+__device__ __noinline__ double sdp_eval_call(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+    return sdp_eval_x<T, Q, EXACT>(w, pt, sweeps, mode);
+}
+template <int T, int Q, bool EXACT>
+__device__ __noinline__ int sdp_newton_dir_call(const SdpWork w) { return sdp_newton_dir_x<T, Q, EXACT>(w); }
+
 template <int T, int Q>
 __device__ __forceinline__ int sdp_factor(const SdpWork w) {
-    if constexpr (Q > 0) return (w.q == Q) ? sdp_factor_reg<Q, true>(w) : sdp_factor_reg<Q, false>(w);
-    else return 0;                       // the LDS path keeps S itself
+    if constexpr (Q > 0) return (w.q == Q) ? sdp_factor_call<T, Q, true>(w) : sdp_factor_call<T, Q, false>(w);
+    else return 0;
 }
 template <int T, int Q>
 __device__ __forceinline__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     if constexpr (Q > 0)
-        return (w.q == Q) ? sdp_eval_reg<Q, true>(w, pt, sweeps, mode) : sdp_eval_reg<Q, false>(w, pt, sweeps, mode);
+        return (w.q == Q) ? sdp_eval_call<T, Q, true>(w, pt, sweeps, mode) : sdp_eval_call<T, Q, false>(w, pt, sweeps, mode);
     else return sdp_eval_lds<T>(w, pt, sweeps);
 }
 template <int T, int Q>
 __device__ __forceinline__ int sdp_newton_dir(const SdpWork w) {
-    if constexpr (Q > 0) return (w.q == Q) ? sdp_newton_dir_reg<Q, true>(w) : sdp_newton_dir_reg<Q, false>(w);
+    if constexpr (Q > 0) return (w.q == Q) ? sdp_newton_dir_call<T, Q, true>(w) : sdp_newton_dir_call<T, Q, false>(w);
     else return sdp_newton_dir_lds<T>(w);
 }
 
@@ -881,8 +908,10 @@ __device__ __forceinline__ int sdp_newton_dir(const SdpWork w) {
 // Full solve.  On entry w.S (symmetric) and w.dl are set.  On exit w.p holds the optimum and the
 // state (U in w.X, sv, sq, rp, ip, s) belongs to it.  Returns status; *g_out = max g.
 // ================================================================================================
-template <int T, int Q>
-__device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
+// The loop is written as a state machine so that the evaluation has a single (inlined) call site:
+// first the start point, then one or more trial points per Newton iteration.
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, int* iters_out) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     // start: the closed-form q = 1 weights, shrunk into the simplex
@@ -901,15 +930,42 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
 #ifdef OEI_SDP_TIMING
     if (tid == 0) { for (int i = 0; i < 8; ++i) w.scal[i] = 0.0; }
 #endif
-    if (sdp_factor<T, Q>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
-    double g = sdp_eval<T, Q>(w, w.p, sweeps, SDP_EVAL_LOOSE);
-    if (!(g > -INFINITY)) { *g_out = g; *iters_out = 0; return 2; }
-    for (it = 1; it <= SDP_MAX_NEWTON; ++it) {
+    if (sdp_factor_call<T, Q, EXACT>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
+    double g = -INFINITY, t = 1.0, dec = 0.0, slack = 0.0, rel = 1.0;
+    bool first = true, full = true;
+    int ls = 0;
+    for (;;) {
+        // evaluations that only steer the iteration run with the loose Jacobi tolerance; the one
+        // after a step below the stopping tolerance is the final state and runs tight
+        const int mode = first ? SDP_EVAL_LOOSE
+                               : (SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
+        const double gv = sdp_eval_call<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
+        if (first) {
+            first = false;
+            g = gv;
+            if (!(g > -INFINITY)) { status = 2; break; }
+        } else {
+            if (!(gv >= g + 1e-4 * t * dec - slack) && ++ls < 40) {     // backtrack
+                t *= 0.5; full = false;
+                __syncthreads();
+                if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
+                __syncthreads();
+                continue;
+            }
+            __syncthreads();
+            if (tid < q) w.p[tid] = w.pn[tid];
+            __syncthreads();
+            g = gv;
+            if (!(g > -INFINITY)) { status = 2; break; }
+            if (full && rel < SDP_STEP_TOL) { status = 0; break; }
+        }
+        if (++it > SDP_MAX_NEWTON) break;
         SDP_TIC(t_dir);
-        const int dir_fail = sdp_newton_dir<T, Q>(w);
+        const int dir_fail = sdp_newton_dir_call<T, Q, EXACT>(w);
         SDP_TOC(3, t_dir);
         if (dir_fail) { status = 2; break; }
-        double rel = 0.0, ssum = 0.0, dec = 0.0, psum = 0.0;
+        double ssum = 0.0, psum = 0.0;
+        rel = 0.0; dec = 0.0;
         for (int i = 0; i < q; ++i) {
             const double st = w.step[i];
             rel = fmax(rel, fabs(st) / w.p[i]);
@@ -918,28 +974,27 @@ __device__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
         }
         rel = fmax(rel, fabs(ssum) / (1.0 - psum));
         if (!(rel == rel)) { status = 2; break; }
-        double t = rel < 0.9 ? 1.0 : 0.9 / rel;
-        const double slack = 1e-14 * (1.0 + fabs(g));
-        double gn = -INFINITY;
-        bool full = (t == 1.0);
-        for (int ls = 0; ls < 40; ++ls) {
-            __syncthreads();
-            if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
-            __syncthreads();
-            gn = sdp_eval<T, Q>(w, w.pn, sweeps, SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
-            if (gn >= g + 1e-4 * t * dec - slack) break;
-            t *= 0.5; full = false;
-        }
+        t = rel < 0.9 ? 1.0 : 0.9 / rel;
+        slack = 1e-14 * (1.0 + fabs(g));
+        full = (t == 1.0);
+        ls = 0;
         __syncthreads();
-        if (tid < q) w.p[tid] = w.pn[tid];
+        if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];
         __syncthreads();
-        g = gn;
-        if (!(g > -INFINITY)) { status = 2; break; }
-        if (full && rel < SDP_STEP_TOL) { status = 0; break; }
     }
     *g_out = g;
     *iters_out = (it & 0xffff) | (sweeps << 16);
     return status;
+}
+
+template <int T, int Q>
+__device__ __forceinline__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
+    if constexpr (Q > 0) {
+        return (w.q == Q) ? sdp_solve_impl<T, Q, true>(w, g_out, iters_out)
+                          : sdp_solve_impl<T, Q, false>(w, g_out, iters_out);
+    } else {
+        return sdp_solve_impl<T, 0, false>(w, g_out, iters_out);
+    }
 }
 
 // ---- outputs from the final state ---------------------------------------------------------------

@@ -26,16 +26,28 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = fp64 matrix peak (datasheet)
 
 def flops_model(q, n, npad, newton_iters, sweeps):
     """Algorithmic flops of the moments+SDP kernel for one candidate (fma = 2 flops), from the
-    counters the solver returns.  Terms: posterior moments and Z (n-length reductions), per
-    objective evaluation, per Jacobi sweep, per Newton direction."""
-    np_ = (q + 1) // 2
-    per_sweep = (q + (q & 1) - 1) * (np_ * np_ * 24 + q * np_ * 6)
-    per_eval = 20 * q * q
-    per_dir = 6 * q * q + 4 * q ** 3 + 1.5 * q ** 3 + 0.75 * q ** 4 + q ** 3 / 3 + 2 * q * q
+    counters the solver returns (register path, q <= 32).  Useful work only: padding lanes and
+    the repeated rotation-parameter arithmetic in idle lanes are not counted.
+      moments   posterior mean and covariance: n-length dot products for q(q+1)/2 + q pairs
+      zmat      Z = M11 A: q^2 multiply-adds for each of npad columns
+      factor    Cholesky of the q x q covariance, once
+      per_eval  m = Lc^T p, G, the warm-start product G V (2 q^3), back substitution (q^3),
+                gradient (3 q^2)
+      per_sweep one-sided Jacobi: q(q-1)/2 pairs x (dot product 2q + two column updates 6q +
+                about 30 for the rotation) + refresh of the norms (2 q^2)
+      per_dir   q(q+1)/2 + q + 1 quadratic forms of q^2 + 6q flops, kernel q^2, Cholesky q^3/3,
+                two triangular solves 2 q^2
+    """
+    qe = q + (q & 1)
+    per_sweep = (qe - 1) * (qe // 2) * (8 * q + 30) + 2 * q * q
+    per_eval = 3 * q ** 3 + 6 * q * q
+    nitems = q * (q + 1) // 2 + q + 1
+    per_dir = nitems * (q * q + 6 * q) + q * q + q ** 3 / 3 + 2 * q * q
     moments = 2 * n * (q * (q + 1) / 2 + q)
     zmat = 2 * q * q * npad
+    factor = q ** 3 / 3
     evals = newton_iters + 1
-    return moments + zmat + evals * per_eval + sweeps * per_sweep + newton_iters * per_dir
+    return moments + zmat + factor + evals * per_eval + sweeps * per_sweep + newton_iters * per_dir
 
 
 def cpu_baseline(model, X_sample, seconds_hint=20.0):
