@@ -44,6 +44,7 @@
 #define SDP_MAX_SWEEPS 30
 #define SDP_JACOBI_TOL 1e-15
 #define SDP_STEP_TOL 1e-7
+#define SDP_DECREMENT_TOL 1e-19
 #define SDP_JACOBI_FINAL 1e-7
 // evaluations that only steer the Newton iteration (every one but the last) stop earlier
 #define SDP_JACOBI_TOL_LOOSE 1e-11
@@ -167,6 +168,11 @@ __device__ int sdp_jacobi(const SdpWork w) {
     const int qe = q + (q & 1), np = qe >> 1, nm1 = qe - 1;
     lds_f64* X = w.X;
     lds_f64* V = w.V;
+    // Off-diagonal entries below the rounding level of the largest diagonal entry are noise that
+    // later rotations keep re-creating: rotating them away would never end.
+    double xmax = 0.0;
+    for (int i = 0; i < q; ++i) xmax = fmax(xmax, X[i * LD + i]);
+    const double floor2 = (4.0e-16 * xmax) * (4.0e-16 * xmax);
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
         int rotated = 0;
@@ -181,7 +187,7 @@ __device__ int sdp_jacobi(const SdpWork w) {
                 if (j < q) {
                     const double xii = X[i * LD + i], xjj = X[j * LD + j], xij = X[i * LD + j];
                     const double thr = SDP_JACOBI_TOL * SDP_JACOBI_TOL * fabs(xii * xjj);
-                    if (xij * xij > thr && xij != 0.0) {
+                    if (xij * xij > thr && xij * xij > floor2) {
                         const double zeta = (xjj - xii) / (2.0 * xij);
                         t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                         if (zeta < 0.0) t = -t;
@@ -932,7 +938,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
 #endif
     if (sdp_factor_call<T, Q, EXACT>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
     double g = -INFINITY, t = 1.0, dec = 0.0, slack = 0.0, rel = 1.0;
-    bool first = true, full = true;
+    bool first = true, full = true, finish = false;
     int ls = 0;
     for (;;) {
         // evaluations that only steer the iteration run with the loose Jacobi tolerance; the one
@@ -957,7 +963,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
             __syncthreads();
             g = gv;
             if (!(g > -INFINITY)) { status = 2; break; }
-            if (full && rel < SDP_STEP_TOL) { status = 0; break; }
+            if (finish || (full && rel < SDP_STEP_TOL)) { status = 0; break; }
         }
         if (++it > SDP_MAX_NEWTON) break;
         SDP_TIC(t_dir);
@@ -977,6 +983,10 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         t = rel < 0.9 ? 1.0 : 0.9 / rel;
         slack = 1e-14 * (1.0 + fabs(g));
         full = (t == 1.0);
+        // second stopping rule: a Newton decrement below rounding level.  Weights that vanish at
+        // the optimum keep a large relative step for ever; the objective cannot improve any more.
+        // One evaluation at the current point with the tight tolerance leaves the final state.
+        if (dec <= SDP_DECREMENT_TOL * (1.0 + fabs(g))) { finish = true; rel = 0.0; t = 0.0; }
         ls = 0;
         __syncthreads();
         if (tid < q) w.pn[tid] = w.p[tid] + t * w.step[tid];

@@ -281,7 +281,10 @@ def sdp_exact(omega, fmin, tol=1e-10, checkpoints=(100, 200, 400, 800, 1600, 320
         _, M, Y, C, info = sdp_first_order(omega, fmin, eps=1e-9, max_iters=cp - done,
                                            return_info=True, warm=warm)
         warm, done = info['warm'], cp
-        obj, Mp, Yp, ys, res = kkt_polish(omega, fmin, M, Y, iters=30)
+        try:
+            obj, Mp, Yp, ys, res = kkt_polish(omega, fmin, M, Y, iters=30)
+        except np.linalg.LinAlgError:      # singular KKT matrix at this iterate: iterate further
+            continue
         if np.all(np.isfinite(Mp)):
             cm = _cert_max(kkt_certificate(omega, fmin, Mp, Yp))
             if best is None or cm < best[0]:

@@ -1,0 +1,146 @@
+"""GPU parity across the solver's size classes and input shapes.
+
+The device solver has one register-path instance per padded size (8, 16, 20, 32; exact and padded
+variants of each) and an LDS path for q > 32; the kernels around it are specialised for d = 6 and
+generic otherwise.  Every class is run here through the C ABI and checked with the
+solver-independent KKT certificate (full reference-form M and Y), against the CPU restatement of
+the reduced problem, and -- for the gradient -- against d<Omega(X), M>/dX of the oracle's GP.
+Task bars: 1e-5 relative on the value, 1e-4 on the gradient, 1e-3 on Hessian entries; the
+assertions are tighter and say so.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gp as ogp, hart6, oei as ooei, reduced_newton, sdp_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, d=6, kind=ogp.KERNEL_MATERN32, floor_mode=None, seed=0, lengthscale=0.5):
+    from bayesian_optimization_amd import DeviceGP
+    om = hart6.make_model(n, d=d, train_seed=seed, kind=kind, floor_mode=floor_mode,
+                          lengthscale=lengthscale)
+    dm = DeviceGP(om.X, om.y, kind, om.kernel.variance, om.kernel.lengthscales, om.noise,
+                  floor_mode=om.kernel.floor_mode)
+    return om, dm
+
+
+def _check_batch(om, dm, Xs, cert_tol=1e-8):
+    from bayesian_optimization_amd import sdp_batched
+    B = Xs.shape[0]
+    value, grad, status, flags = [t.cpu().numpy() for t in dm.value_grad(Xs)]
+    assert (status == 0).all(), status
+    omg = dm.omega(Xs)
+    v2, M, Y, st2, _ = [t.cpu().numpy() for t in sdp_batched(omg, dm.fmin)]
+    assert (st2 == 0).all()
+    assert np.allclose(v2, value, rtol=1e-10, atol=1e-13)
+    for b in range(B):
+        o = omg[b].cpu().numpy()
+        assert np.allclose(o, om.omega(Xs[b]), rtol=1e-8, atol=1e-9)
+        cert = sdp_ref.kkt_certificate(o, dm.fmin, M[b], list(Y[b]))
+        assert max(v for k, v in cert.items() if k not in ('pobj', 'dobj')) < cert_tol, cert
+        obj = reduced_newton.solve(o, dm.fmin)[0]
+        assert abs(value[b] - obj) <= 1e-9 * abs(obj)                      # task bar: 1e-5
+        _, g0 = om.inner_and_grad(Xs[b], M[b])
+        assert np.abs(grad[b] - g0).max() <= 1e-7 * (1e-12 + np.abs(g0).max())   # task bar: 1e-4
+    return value, grad
+
+
+@pytest.mark.parametrize('q', [2, 7, 8, 9, 16, 17, 19, 21, 32, 33, 40])
+def test_value_grad_size_classes(cuda, q):
+    """One padded and one exact member of every register-path class, both sides of the switch to
+    the LDS path, odd and even q."""
+    om, dm = _mk(60)
+    Xs = np.random.RandomState(31 + q).uniform(-.5, .5, (3, q, 6))
+    _check_batch(om, dm, Xs)
+
+
+def test_value_grad_cfg3_shape(cuda):
+    """The largest configuration of the benchmark table: n = 1000, q = 50, d = 10 (LDS path,
+    generic-dimension kernels)."""
+    om, dm = _mk(1000, d=10, lengthscale=0.8)
+    Xs = np.random.RandomState(41).uniform(-.5, .5, (2, 50, 10))
+    _check_batch(om, dm, Xs, cert_tol=1e-7)
+
+
+@pytest.mark.parametrize('n,d,kind,fm,ls', [(20, 3, ogp.KERNEL_RBF, 0, 0.3),
+                                             (80, 10, ogp.KERNEL_MATERN32, 1, 0.6)])
+def test_other_dimensions_value_grad_hessian(cuda, n, d, kind, fm, ls):
+    """Dimensions other than 6 (generic-dimension kernels).  The d = 3 model is kept small: with
+    many points the posterior covariance drops to the noise level and the oracle's first-order
+    solve (the checker, not the device path) no longer converges."""
+    om, dm = _mk(n, d=d, kind=kind, floor_mode=fm, lengthscale=ls)
+    oracle = ooei.OEIOracle(om)
+    q = 4
+    Xs = np.random.RandomState(43).uniform(-.5, .5, (2, q, d))
+    _check_batch(om, dm, Xs)
+    H, status = dm.hessian(Xs)
+    H = H.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for b in range(2):
+        Href = oracle.acquisition_hessian(Xs[b].ravel())
+        scale = np.abs(Href).max()
+        assert np.abs(H[b] - Href).max() <= 1e-6 * scale                   # task bar: 1e-3
+
+
+def test_hessian_lds_path(cuda):
+    """acquisition_hessian for q > 32 (256-thread kernels) against the oracle."""
+    om, dm = _mk(50)
+    oracle = ooei.OEIOracle(om)
+    q = 33
+    Xs = np.random.RandomState(47).uniform(-.5, .5, (1, q, 6))
+    H, status = dm.hessian(Xs)
+    H = H.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    Href = oracle.acquisition_hessian(Xs[0].ravel())
+    scale = np.abs(Href).max()
+    assert np.abs(H[0] - H[0].T).max() <= 1e-8 * scale
+    assert np.abs(H[0] - Href).max() <= 1e-6 * scale
+
+
+@pytest.mark.parametrize('B', [0, 1, 3, 65, 257])
+def test_ragged_and_empty_batches(cuda, B):
+    """Batch sizes that are not multiples of anything the kernels tile by, and the empty batch;
+    each candidate's result must not depend on its neighbours."""
+    om, dm = _mk(25)
+    q = 5
+    Xall = np.random.RandomState(53).uniform(-.5, .5, (257, q, 6))
+    value, grad, status, flags = dm.value_grad(Xall[:B])
+    assert value.shape == (B,) and grad.shape == (B, q, 6) and status.shape == (B,)
+    if B == 0:
+        H, st = dm.hessian(Xall[:0])
+        assert H.shape == (0, q * 6, q * 6)
+        return
+    ref_v, ref_g, _, _ = dm.value_grad(Xall[:1])
+    assert (status.cpu().numpy() == 0).all()
+    assert torch.equal(value[:1], ref_v) and torch.equal(grad[:1], ref_g)
+    full = dm.value_grad(Xall)[0]
+    assert torch.equal(value, full[:B])
+
+
+def test_sdp_batched_mixed_conditioning(cuda):
+    """Stand-alone SDP on generic (non-GP) inputs of several sizes, including nearly singular
+    covariance blocks and widely spread means.  The register path (q <= 32) works on a square
+    root of the covariance and keeps its accuracy down to a ridge of 1e-8; the LDS path
+    diagonalises the covariance-sized matrix itself and is exercised with a ridge of 1e-5."""
+    from bayesian_optimization_amd import sdp_batched
+    rs = np.random.RandomState(59)
+    for k in (3, 8, 20, 33):
+        oms, fms = [], []
+        for trial in range(6):
+            tmp = rs.randn(k, k) * (10.0 ** rs.uniform(-2, 1))
+            sigma = tmp.dot(tmp.T) + ((1e-8 if k <= 32 else 1e-5) if trial % 2 else 1e-2) * np.eye(k)
+            mu = rs.randn(k) * (10.0 ** rs.uniform(-1, 1))
+            o = np.zeros((k + 1, k + 1))
+            o[:k, :k] = sigma + np.outer(mu, mu)
+            o[-1, :k] = o[:k, -1] = mu
+            o[-1, -1] = 1.0
+            oms.append(o)
+            fms.append(rs.randn())
+        oms, fms = np.stack(oms), np.array(fms)
+        value, M, Y, status, _ = [t.cpu().numpy() for t in sdp_batched(oms, fms)]
+        assert (status == 0).all(), (k, status)
+        for b in range(len(fms)):
+            cert = sdp_ref.kkt_certificate(oms[b], fms[b], M[b], list(Y[b]))
+            assert max(v for kk, v in cert.items() if kk not in ('pobj', 'dobj')) < 1e-7, (k, b, cert)
