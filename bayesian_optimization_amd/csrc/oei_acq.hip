@@ -16,7 +16,7 @@
 // Posterior moments of candidate b into LDS: w.S = Sigma + noise I (full, symmetric), mu[].
 // xq [q][d] must already be in LDS.  Ac is a [q][CH+1] staging buffer, vc a [CH] one.
 template <int T>
-__device__ void posterior_moments(const SdpWork w, const KernParams& kp, double noise, int n,
+__device__ __forceinline__ void posterior_moments(const SdpWork w, const KernParams& kp, double noise, int n,
                                   int npad, size_t astride, const double* __restrict__ Arows,
                                   const double* __restrict__ v, const lds_f64* xq, lds_f64* mu,
                                   lds_f64* Ac, lds_f64* vc) {

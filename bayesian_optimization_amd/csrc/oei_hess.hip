@@ -174,7 +174,7 @@ __device__ __forceinline__ double gsym(const double* __restrict__ Gb, int RP, in
 // mu[a], DS[a][l][b] = d Sigma_ab / d x_al (b == a: the full derivative of Sigma_aa),
 // dmuT[a][l] = d mu_a / d x_al, k1s[a][b] = 2 var kappa'(t_ab), k2s[a][b] = 4 var kappa''(t_ab).
 template <int T>
-__device__ void build_tables(const KernParams& kp, int q, const lds_f64* xq,
+__device__ __forceinline__ void build_tables(const KernParams& kp, int q, const lds_f64* xq,
                              const double* __restrict__ Gb, int RP, lds_f64* mu, lds_f64* DS,
                              lds_f64* dmuT, lds_f64* k1s, lds_f64* k2s) {
     const int tid = threadIdx.x, d = kp.d, dp = d + 1, vrow = q * dp;

@@ -936,7 +936,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
 #ifdef OEI_SDP_TIMING
     if (tid == 0) { for (int i = 0; i < 8; ++i) w.scal[i] = 0.0; }
 #endif
-    if (sdp_factor_call<T, Q, EXACT>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
+    if (sdp_factor_x<T, Q, EXACT>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
     double g = -INFINITY, t = 1.0, dec = 0.0, slack = 0.0, rel = 1.0;
     bool first = true, full = true, finish = false;
     int ls = 0;
@@ -945,7 +945,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         // after a step below the stopping tolerance is the final state and runs tight
         const int mode = first ? SDP_EVAL_LOOSE
                                : (SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
-        const double gv = sdp_eval_call<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
+        const double gv = sdp_eval_x<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
         if (first) {
             first = false;
             g = gv;
@@ -967,7 +967,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         }
         if (++it > SDP_MAX_NEWTON) break;
         SDP_TIC(t_dir);
-        const int dir_fail = sdp_newton_dir_call<T, Q, EXACT>(w);
+        const int dir_fail = sdp_newton_dir_x<T, Q, EXACT>(w);
         SDP_TOC(3, t_dir);
         if (dir_fail) { status = 2; break; }
         double ssum = 0.0, psum = 0.0;
@@ -1050,4 +1050,4 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
         else if ((q) <= 20) { CALL(64, 20); } else if ((q) <= 32) { CALL(64, 32); } \
         else { CALL(256, 0); } } while (0)
 // waves per SIMD the register budget is tuned for (launch bound of the solver kernels)
-#define SDP_MIN_WAVES(Q) ((Q) == 0 ? 1 : (Q) <= 20 ? 3 : 2)
+#define SDP_MIN_WAVES(Q) ((Q) == 0 ? 1 : 2)
