@@ -170,7 +170,7 @@ def main():
                     'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
         cpu = None
         if not args.no_cpu_baseline:
-            v, done, secs = cpu_baseline(model, X_local[:4].cpu().numpy())
+            v, done, secs = cpu_baseline(model, X_local[:24].cpu().numpy())
             cpu = {'value': v, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
                    'sample': '%d candidate batches (q=%d, n=%d) of the same workload, one at a time, '
                              'numpy restatement of the reference path with the first-order SDP solve '
