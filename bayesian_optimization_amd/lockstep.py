@@ -1,0 +1,165 @@
+"""Lock-step multistart descent: many bounded quasi-Newton runs advanced together.
+
+The reference optimises the acquisition function from `opt_restarts` random starts one after the
+other, each with scipy's L-BFGS-B calling `acquisition` once per function evaluation
+(bo.py:129-192, solvers.py:10-21).  The starts are independent, so here all of them step in
+lock-step: one batched value+gradient call per line-search trial serves every run that still needs
+one.  The iterates, the limited-memory pairs and all vector arithmetic stay on the device that the
+evaluations run on; the host only sees a few scalars per iteration (how many runs are still active).
+
+Method per run (the same for all, vectorised over the batch):
+  * projected gradient test  max|x - P(x - g)| <= pgtol  (the stopping rule of L-BFGS-B, `pgtol`)
+    and relative decrease  (f - f+) <= ftol max(|f|, |f+|, 1)  (`factr * epsmch`);
+  * direction d = -H g restricted to the variables not blocked at a bound (lower bound with
+    g > 0 or upper bound with g < 0), H the two-loop L-BFGS operator over the last `history`
+    curvature pairs; steepest descent if d is not a descent direction;
+  * projected backtracking line search  x+ = P(x + t d),  accept when
+    f(x+) <= f(x) + c1 g.(x+ - x);  pairs (s, y) are stored when s.y > 1e-10 |s||y|.
+This is a projected L-BFGS, not a port of the Fortran L-BFGS-B (no generalised Cauchy point, no
+subspace minimisation); iterates differ from scipy's, local optima found from the same start are
+the same in the tests.
+"""
+from collections import namedtuple
+
+import torch
+
+LockstepResult = namedtuple('LockstepResult', 'x fun grad nit nfev converged message')
+
+
+def minimize_lockstep(fun, X0, lower, upper, history=10, max_iter=200, pgtol=1e-5, ftol=2.2e-9,
+                      c1=1e-4, max_ls=25):
+    """Minimise `fun` from every row of X0 [B, n] inside the box [lower, upper] (tensors [n] or
+    scalars).  `fun(X[b, n]) -> (f[b], g[b, n])` is called with sub-batches (only the runs that
+    need an evaluation) and may return +inf / NaN for points it cannot evaluate (they are
+    rejected by the line search).  Returns LockstepResult with per-run fields."""
+    x = torch.as_tensor(X0).clone()
+    B, n = x.shape
+    dev, dt = x.device, x.dtype
+    lo = torch.as_tensor(lower, dtype=dt, device=dev).expand(n).clone()
+    hi = torch.as_tensor(upper, dtype=dt, device=dev).expand(n).clone()
+    x = torch.minimum(torch.maximum(x, lo), hi)
+    f, g = fun(x)
+    f = f.clone()
+    g = g.clone().reshape(B, n)
+    nfev = torch.ones(B, dtype=torch.int64, device=dev)
+    nit = torch.zeros(B, dtype=torch.int64, device=dev)
+    bad0 = ~torch.isfinite(f)
+    S = torch.zeros((B, history, n), dtype=dt, device=dev)
+    Y = torch.zeros((B, history, n), dtype=dt, device=dev)
+    rho = torch.zeros((B, history), dtype=dt, device=dev)
+    gamma = torch.ones(B, dtype=dt, device=dev)
+    done = bad0.clone()
+    converged = torch.zeros(B, dtype=torch.bool, device=dev)
+    first = torch.ones(B, dtype=torch.bool, device=dev)
+    slot = 0
+    for _ in range(max_iter):
+        pg = x - torch.minimum(torch.maximum(x - g, lo), hi)
+        hit = (pg.abs().amax(dim=1) <= pgtol) & ~done
+        converged |= hit
+        done |= hit
+        if bool(done.all()):
+            break
+        free = ~(((x <= lo) & (g > 0)) | ((x >= hi) & (g < 0)))
+        fm = free.to(dt)
+        # two-loop recursion, newest pair first (ring buffer: slot-1, slot-2, ...)
+        q = g * fm
+        alphas = []
+        order = [(slot - 1 - i) % history for i in range(history)]
+        for i in order:
+            a = rho[:, i] * (S[:, i] * q).sum(dim=1)
+            alphas.append(a)
+            q = q - a[:, None] * Y[:, i]
+        r = gamma[:, None] * q
+        for i, a in zip(reversed(order), reversed(alphas)):
+            b = rho[:, i] * (Y[:, i] * r).sum(dim=1)
+            r = r + (a - b)[:, None] * S[:, i]
+        d = -r * fm
+        gd = (g * d).sum(dim=1)
+        reset = ~(gd < 0)
+        if bool(reset.any()):
+            d = torch.where(reset[:, None], -g * fm, d)
+            gd = (g * d).sum(dim=1)
+        dn = d.norm(dim=1)
+        t = torch.where(first, torch.clamp(1.0 / torch.clamp(dn, min=1e-300), max=1.0), torch.ones_like(dn))
+        need = ~done & (dn > 0)
+        stalled = ~done & ~(dn > 0)
+        done |= stalled
+        x_new, f_new, g_new = x.clone(), f.clone(), g.clone()
+        accepted = torch.zeros(B, dtype=torch.bool, device=dev)
+        for _ls in range(max_ls):
+            idx = torch.nonzero(need & ~accepted).reshape(-1)
+            if idx.numel() == 0:
+                break
+            xt = torch.minimum(torch.maximum(x[idx] + t[idx, None] * d[idx], lo), hi)
+            ft, gt = fun(xt)
+            gt = gt.reshape(idx.numel(), n)
+            nfev[idx] += 1
+            ok = ft <= f[idx] + c1 * (g[idx] * (xt - x[idx])).sum(dim=1)      # False for NaN / inf
+            oki = idx[ok]
+            x_new[oki], f_new[oki], g_new[oki] = xt[ok], ft[ok], gt[ok]
+            accepted[oki] = True
+            t[idx[~ok]] *= 0.5
+        failed = need & ~accepted
+        done |= failed
+        s = x_new - x
+        y = g_new - g
+        sy = (s * y).sum(dim=1)
+        valid = accepted & (sy > 1e-10 * s.norm(dim=1) * y.norm(dim=1))
+        S[:, slot] = torch.where(valid[:, None], s, torch.zeros_like(s))
+        Y[:, slot] = torch.where(valid[:, None], y, torch.zeros_like(y))
+        rho[:, slot] = torch.where(valid, 1.0 / torch.where(valid, sy, torch.ones_like(sy)), torch.zeros_like(sy))
+        gamma = torch.where(valid, sy / torch.clamp((y * y).sum(dim=1), min=1e-300), gamma)
+        slot = (slot + 1) % history
+        small = accepted & ((f - f_new) <= ftol * torch.maximum(torch.maximum(f.abs(), f_new.abs()),
+                                                                 torch.ones_like(f)))
+        converged |= small
+        done |= small
+        nit += accepted.to(torch.int64)
+        first &= ~accepted
+        x, f, g = x_new, f_new, g_new
+    message = ['converged' if c else ('no finite start value' if b else 'stopped')
+               for c, b in zip(converged.tolist(), bad0.tolist())]
+    return LockstepResult(x=x, fun=f, grad=g, nit=nit, nfev=nfev, converged=converged, message=message)
+
+
+def acquisition_fun(gp, q, project_fallback=None):
+    """Adapter from a DeviceGP to the `fun` of minimize_lockstep: X [b, q*d] -> (value, grad).
+    Candidates whose SDP did not solve get +inf (the line search then backs off).
+    `project_fallback(X_row numpy) -> (value, grad numpy)` re-evaluates candidates that the
+    duplicate test of the reference's `project` (oei.py:157-199) flags."""
+    d = gp.dim
+
+    def fun(X):
+        b = X.shape[0]
+        value, grad, status, flags = gp.value_grad(X.reshape(b, q, d), want_flags=project_fallback is not None)
+        grad = grad.reshape(b, q * d)
+        value = torch.where(status == 0, value, torch.full_like(value, float('inf')))
+        if project_fallback is not None and bool(flags.any()):
+            for i in torch.nonzero(flags).reshape(-1).tolist():
+                v, gr = project_fallback(X[i].cpu().numpy())
+                value[i] = float(v)
+                grad[i] = torch.as_tensor(gr, dtype=grad.dtype, device=grad.device)
+        return value, grad
+    return fun
+
+
+def optimize_multistart(gp, X_starts, lower, upper, index_base=0, group=None, project_fallback=None,
+                        **kwargs):
+    """Lock-step descent from the local shard of starts X_starts [B, q, d], then the global best
+    over all ranks (one all-gather of a (value, index, X) record, see multistart.select_best).
+    Returns (LockstepResult of the local shard, (best_value, best_index, best_X [q, d]))."""
+    from . import engine, multistart
+    B, q, d = X_starts.shape
+    X0 = torch.as_tensor(X_starts, dtype=torch.float64, device=gp.device).reshape(B, q * d)
+    lo = torch.as_tensor(lower, dtype=torch.float64, device=gp.device)
+    hi = torch.as_tensor(upper, dtype=torch.float64, device=gp.device)
+    if lo.numel() == d:
+        lo, hi = lo.repeat(q), hi.repeat(q)
+    res = minimize_lockstep(acquisition_fun(gp, q, project_fallback), X0, lo, hi, **kwargs)
+    fv = torch.where(torch.isfinite(res.fun), res.fun, torch.full_like(res.fun, float('nan')))
+    bv, bi = engine.argmin(fv, index_base)
+    local = torch.clamp(bi - index_base, min=0)
+    Xb = res.x.index_select(0, local.reshape(1)).reshape(-1)
+    rec = multistart.make_record(bv, bi, Xb)
+    best_value, best_index, best_X = multistart.select_best(rec, group)
+    return res, (best_value, best_index, best_X.reshape(q, d))

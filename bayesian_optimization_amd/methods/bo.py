@@ -122,6 +122,8 @@ class BO(object):
 
     def get_suggestion(self, batch_size):
         """bo.py:129-192: multistart descent on the acquisition function."""
+        if self.options['nl_solver'] == 'lockstep':
+            return self._get_suggestion_lockstep(batch_size)
         X, y = None, None
         bounds_tiled = np.tile(self.bounds, (batch_size, 1))
         for j in range(self.options['opt_restarts']):
@@ -133,11 +135,28 @@ class BO(object):
             if X is None or y0 < y:
                 X, y = X0, y0
             logging.getLogger('opt').info('##Opt_it:' + str(j + 1) + ' Val:' + '%.2e' % y0 +
-                                          ' Diff:' + '%.2e' % (y_init - y0) + ' It:' + str(status.nit))
+                                          ' Diff:' + '%.2e' % float(np.ravel(y_init - y0)[0]) + ' It:' + str(status.nit))
             if not status.success:
                 logging.getLogger('opt').warning('NLP Warning:' + str(status.message))
         assert X is not None
         return X
+
+    def _get_suggestion_lockstep(self, batch_size):
+        """The multistart loop of bo.py:129-192 with all `opt_restarts` descents advanced together
+        (lockstep.py): same random starts in the same order of the np.random stream, the best
+        final point wins."""
+        from .. import lockstep
+        starts = np.stack([self.random_sample(self.bounds, batch_size)
+                           for _ in range(self.options['opt_restarts'])])
+        res, best = lockstep.optimize_multistart(
+            self.device_model(), starts, self.bounds[:, 0], self.bounds[:, 1],
+            project_fallback=lambda x: (lambda r: (r[0][0], r[1]))(self.acquisition(x)))
+        log = logging.getLogger('opt')
+        fun, nit = res.fun.cpu().numpy(), res.nit.cpu().numpy()
+        for j in range(len(fun)):
+            log.info('##Opt_it:' + str(j + 1) + ' Val:' + '%.2e' % fun[j] + ' It:' + str(int(nit[j])))
+        assert int(best[1].item()) >= 0
+        return best[2].cpu().numpy()
 
     def optimize_restarts(self, restarts=1, **kwargs):
         """Hyper-parameter fit of bo.py:194-221.  The reference maximises the GP marginal likelihood
