@@ -522,6 +522,74 @@ __device__ __forceinline__ int sdp_factor_reg(const SdpWork w) {
     return fail;
 }
 
+// Split layout of the Jacobi iteration: column j of G is spread over the P = 64/Q lanes j, j+Q, ...,
+// each holding RS = ceil(Q/P) consecutive rows, so that (nearly) all 64 lanes work on the
+// rotations instead of Q of them.  Sums over a column are formed in one fixed order in every lane
+// of the column, which keeps the rotation decisions and parameters bit-identical across its parts.
+template <int Q>
+__device__ __forceinline__ double sdp_col_sum(double v, int col) {
+    constexpr int P = 64 / Q;
+    double s = __shfl(v, col, 64);
+#pragma unroll
+    for (int pt = 1; pt < P; ++pt) s += __shfl(v, col + Q * pt, 64);
+    return s;
+}
+
+template <int Q, int RS>
+__device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
+    constexpr int P = 64 / Q;
+    const int lane = threadIdx.x & 63;
+    const int col = lane % Q, part = lane / Q;
+    const int poff = (part < P) ? part * Q : 0;       // left-over lanes hold zeros and read part 0
+    int sweep = 0;
+    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
+        bool rotated = false;
+        double a2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < RS; ++k) a2 += g[k] * g[k];
+        double alpha = sdp_col_sum<Q>(a2, col);
+        // round-robin pairing of the columns: column c < Q-1 meets (2r - c) mod (Q-1), the fixed
+        // point of that map meets column Q-1; `base` follows (2r - c) mod (Q-1) incrementally
+        int base = (col < Q - 1) ? ((Q - 1 - col) % (Q - 1)) : 0;
+        for (int r = 0; r < Q - 1; ++r) {
+            int pc = r;                                // partner of column Q-1
+            if (col < Q - 1) pc = (base == col) ? Q - 1 : base;
+            base += 2;
+            if (base >= Q - 1) base -= Q - 1;
+            const int plane = pc + poff;
+            double pg[RS];
+#pragma unroll
+            for (int k = 0; k < RS; ++k) pg[k] = __shfl(g[k], plane, 64);
+            const double beta = __shfl(alpha, plane, 64);
+            double dot = 0.0;
+#pragma unroll
+            for (int k = 0; k < RS; ++k) dot += g[k] * pg[k];
+            const double gamma = sdp_col_sum<Q>(dot, col) ;
+            const bool low = col < pc;
+            double c = 1.0, sg = 0.0;
+            const double g2 = gamma * gamma, aa = alpha * beta;
+            const bool rot = g2 > tol2 * aa;
+            if (rot) {
+                // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = alpha_j - alpha_i  (i < j)
+                const double d = low ? beta - alpha : alpha - beta;
+                const double x = fma(d, d, 4.0 * g2);
+                const double h = x * sdp_rsq(x);
+                double t = 2.0 * gamma * sdp_rcp(fabs(d) + h);
+                if (d < 0.0) t = -t;
+                c = sdp_rsq(fma(t, t, 1.0));
+                const double ts = low ? -t : t;
+                sg = ts * c;                     // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
+                alpha = fma(ts, gamma, alpha);
+            }
+            rotated |= rot && (g2 > fin2 * aa);
+#pragma unroll
+            for (int k = 0; k < RS; ++k) g[k] = c * g[k] + sg * pg[k];
+        }
+        if (!__any(rotated)) { ++sweep; break; }
+    }
+    return sweep;
+}
+
 // Needs w.S = Lc, w.rc = 1/diag(Lc) (sdp_factor_reg).  With `warm`, the state of the previous
 // evaluation (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in w.sv) seeds this one:
 // G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
@@ -531,8 +599,13 @@ __device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* p
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     SDP_TIC(t_setup);
+    // lane tid serves column `me` (its piece of it during the Jacobi iteration); the lanes
+    // tid < q ("act") own the column for everything else
+    constexpr int P = 64 / Q, RS = (Q + P - 1) / P;
     const bool act = tid < q;
-    const int me = act ? tid : 0;
+    const int part = tid / Q, r0 = part * RS;
+    const bool live = (part < P) && (tid % Q < q);
+    const int me = (tid % Q < q) ? tid % Q : 0;
     const double pme = pt[me];
     double sum, pmin;
     if constexpr (EXACT) {
@@ -564,32 +637,38 @@ __device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* p
         if (act) w.tv[tid] = acc;
     }
     __syncthreads();
-    double g[Q];
-    {   // column j of G = s_j (Lc^T e_j - gam m); lanes >= q hold zero columns
-        const double sj = act ? sme : 0.0;
+    lds_f64* GT = w.H;                  // q x q exchange buffer (w.H is free during an evaluation)
+    double gs[RS];
+    {   // rows r0.. of column j of G = s_j (Lc^T e_j - gam m); idle lanes and padding rows: zeros
+        const double sj = live ? sme : 0.0;
 #pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            if (EXACT || k < q) g[k] = sj * (w.S[me * LD + k] - gam * w.tv[k]);
-            else g[k] = 0.0;
+        for (int k = 0; k < RS; ++k) {
+            const int r = r0 + k;
+            const bool in = r < q;
+            const int rr = in ? r : 0;
+            const double v = w.S[me * LD + rr] - gam * w.tv[rr];
+            gs[k] = in ? sj * v : 0.0;
         }
-        if (EXACT) SDP_READS_FIRST(2 * Q, 4 * Q);
     }
     if (mode & SDP_EVAL_WARM) {
-        lds_f64* GT = w.H;
-        if (act) {
+        if (live) {
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) GT[k * LD + tid] = g[k] * rs_prev;
+            for (int k = 0; k < RS; ++k) { const int r = r0 + k; if (r < q) GT[r * LD + me] = gs[k] * rs_prev; }
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < Q; ++k) g[k] = 0.0;
+        for (int k = 0; k < RS; ++k) gs[k] = 0.0;
 #pragma unroll 2
         for (int j = 0; j < q; ++j) {
             const double vl = fma(sv_prev, w.wp[j], w.X[j * LD + me]);     // s_j V_prev[j][a]
-            const double vj = act ? vl : 0.0;
+            const double vj = live ? vl : 0.0;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) g[k] += GT[k * LD + j] * vj;
-            if (EXACT) SDP_READS_FIRST(Q + 2, 2 * Q + 4);
+            for (int k = 0; k < RS; ++k) {
+                const int r = r0 + k;
+                const double gt = GT[(r < q ? r : 0) * LD + j];
+                gs[k] += (r < q ? gt : 0.0) * vj;
+            }
+            if (EXACT) SDP_READS_FIRST(RS + 2, 3 * RS + 4);
         }
         __syncthreads();
     }
@@ -599,7 +678,7 @@ __device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* p
         const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
         const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
         const double fin = loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
-        sweeps += sdp_jacobi_reg<Q>(g, tol * tol, fin * fin);
+        sweeps += sdp_jacobi_split<Q, RS>(gs, tol * tol, fin * fin);
     }
     SDP_TOC(1, t_jac);
     SDP_TIC(t_rest);
@@ -607,12 +686,25 @@ __device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* p
     int bad = 0;
     double sqv = 0.0, su = 0.0;
     {
-        double u[Q];
-        double nrm = 0.0;
+        double n2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < Q; ++k) nrm += g[k] * g[k];
+        for (int k = 0; k < RS; ++k) n2 += gs[k] * gs[k];
+        const double nrm = sdp_col_sum<Q>(n2, tid % Q);
         if (act && !(nrm > 0.0)) bad = 1;
         sqv = sqrt(fmax(nrm, 1e-300));
+        // gather the pieces of each column into its owning lane
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < RS; ++k) { const int r = r0 + k; if (r < q) GT[r * LD + me] = gs[k]; }
+        }
+        __syncthreads();
+        double g[Q], u[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            if (EXACT || k < q) g[k] = GT[k * LD + me];
+            else g[k] = 0.0;
+        }
+        if (EXACT) SDP_READS_FIRST(Q, Q);
 #pragma unroll
         for (int k = Q - 1; k >= 0; --k) {
             double acc = 0.0;
