@@ -41,14 +41,34 @@ __device__ __forceinline__ void posterior_moments(const SdpWork w, const KernPar
         ii[u] = i; jj[u] = j;
     }
     const int nchunks = (n + CH - 1) / CH;
+    // The A rows of the next chunk travel from HBM into registers while the current chunk is
+    // being reduced: NE elements per thread cover q * CH (q <= 32 with 64 threads, <= 64 with 256).
+    constexpr int NE = (T == 64) ? 32 : 16;
+    double nxt[NE];
+    double vnxt = 0.0;
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if (u * T < q * CH) {                        // uniform
+                const int e = tid + u * T, a = e / CH, k = e - a * CH;
+                nxt[u] = Arows[(size_t)a * astride + c * CH + k];
+            }
+        }
+        if (tid < CH) vnxt = v[c * CH + tid];
+    };
+    fetch(0);
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();
-        for (int e = tid; e < q * CH; e += T) {
-            const int a = e / CH, k = e - a * CH;
-            Ac[a * (CH + 1) + k] = Arows[(size_t)a * astride + c * CH + k];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            if (u * T < q * CH) {
+                const int e = tid + u * T, a = e / CH, k = e - a * CH;
+                Ac[a * (CH + 1) + k] = nxt[u];
+            }
         }
-        for (int k = tid; k < CH; k += T) vc[k] = v[c * CH + k];
+        if (tid < CH) vc[tid] = vnxt;
         __syncthreads();
+        if (c + 1 < nchunks) fetch(c + 1);
 #pragma unroll
         for (int u = 0; u < ITEMS_MAX; ++u) {
             if (u * T >= nitems) break;                  // uniform; idle lanes redo item 0
@@ -200,103 +220,73 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
 }
 
 // ---- gradient -------------------------------------------------------------------------------------
-// For each chunk of CH training points: ck[a][k] = (p_a alpha_k - 2 W[a,k]) * 2 var kappa'(t_ak),
-// then G[a][l] += sum_k ck[a][k] X[k][l] and G[a][d] += sum_k ck[a][k]; finally
-// grad[a][l] = (x_al G[a][d] - G[a][l]) / ls_l^2 + self terms.  Also raises the `project` flag.
-// Thread t owns training point k = t mod CH of the chunk (coordinates in registers when the
-// dimension D is a compile-time constant, D = 0: any dimension, read back from LDS) and walks the
-// candidate's points a = t / CH, t / CH + T / CH, ...; W rows are read coalesced along k.
-template <int T, int D>
+// For each chunk of CH training points: ck[a][k] = (p_a alpha_k - 2 W[a,k]) * K1[a,k] with
+// K1 = 2 var kappa'(t_ak) kept from the Gram kernel, then G[a][l] += sum_k ck[a][k] X[k][l] and
+// G[a][d] += sum_k ck[a][k]; finally grad[a][l] = (x_al G[a][d] - G[a][l]) / ls_l^2 + self terms.
+// Thread t owns training point k = t mod CH of the chunk and walks the candidate's points
+// a = t / CH, t / CH + T / CH, ...; W and K1 rows are read coalesced along k.  Raises the `project`
+// flag for mutual duplicates (the Gram kernel raises it for duplicates of training points).
+template <int T>
 __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int q,
                                             const double* __restrict__ Xtrain,
                                             const double* __restrict__ alpha,
                                             const double* __restrict__ Xq,
                                             const double* __restrict__ Wm,
+                                            const double* __restrict__ K1m,
                                             const double* __restrict__ p_in,
                                             const double* __restrict__ M11_in,
                                             double* __restrict__ grad, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int d = D > 0 ? D : kp.d, dp = d + 1, dl = (d + 1) | 1;
+    const int d = kp.d, dp = d + 1, dl = (d + 1) | 1;
     lds_f64* xq = (lds_f64*)sm;               // [q][d]
     lds_f64* M11 = xq + q * d;                // [q][q]
     lds_f64* pv = M11 + q * q;                // [q]
     lds_f64* ck = pv + q;                     // [q][CH+1]
     lds_f64* Xc = ck + q * (CH + 1);          // [CH][dl]   (column d holds 1)
     lds_f64* Gs = Xc + CH * dl;               // [q][q]     2 var kappa'(t_ab)
+    lds_f64* Gl = Gs + q * q;                 // [q][d+1]   accumulators, one owner thread each
     const int tid = threadIdx.x, b = blockIdx.x;
     for (int e = tid; e < q * d; e += T) xq[e] = Xq[(size_t)b * q * d + e];
     for (int e = tid; e < q * q; e += T) M11[e] = M11_in[(size_t)b * q * q + e];
     for (int e = tid; e < q; e += T) pv[e] = p_in[(size_t)b * q + e];
     __syncthreads();
     const int nitems = q * dp;
-    double acc[ITEMS_MAX];
-#pragma unroll
-    for (int u = 0; u < ITEMS_MAX; ++u) acc[u] = 0.0;
+    for (int e = tid; e < nitems; e += T) Gl[e] = 0.0;
     int flag = 0;
     const double* Wrows = Wm + (size_t)b * q * npad;
+    const double* Krows = K1m + (size_t)b * q * npad;
     const int nchunks = (n + CH - 1) / CH;
     const int k = tid & (CH - 1), ag = tid / CH;
     constexpr int NA = T / CH;
-    const double var2 = 2.0 * kp.variance;
     for (int c = 0; c < nchunks; ++c) {
-        const int kg = c * CH + k;
-        const bool valid = kg < n;
-        double xk[D > 0 ? D : 1];
-        if constexpr (D > 0) {
-#pragma unroll
-            for (int l = 0; l < D; ++l) xk[l] = valid ? Xtrain[(size_t)kg * D + l] : 0.0;
-        }
-        const double al = valid ? alpha[kg] : 0.0;
+        const int kg = c * CH + k;                   // < npad: inside the padded rows of W and K1
+        const double al = (kg < n) ? alpha[kg] : 0.0;
         __syncthreads();                     // the previous chunk's contraction is done
         if (ag == 0) {
-            if constexpr (D > 0) {
-#pragma unroll
-                for (int l = 0; l < D; ++l) Xc[k * dl + l] = xk[l];
-            } else {
-                for (int l = 0; l < d; ++l) Xc[k * dl + l] = valid ? Xtrain[(size_t)kg * d + l] : 0.0;
-            }
+            for (int l = 0; l < d; ++l) Xc[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
             Xc[k * dl + d] = 1.0;
         }
-        if constexpr (D == 0) __syncthreads();
-#pragma unroll 2
+#pragma unroll 4
         for (int a = ag; a < q; a += NA) {
-            const double wv = valid ? Wrows[(size_t)a * npad + kg] : 0.0;
-            double t = 0.0;
-            bool close = true;
-            if constexpr (D > 0) {
-#pragma unroll
-                for (int l = 0; l < D; ++l) {
-                    const double df = xq[a * D + l] - xk[l];
-                    t += df * df * kp.inv_ls2[l];
-                    close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
-                }
-            } else {
-                for (int l = 0; l < d; ++l) {
-                    const double df = xq[a * d + l] - Xc[k * dl + l];
-                    t += df * df * kp.inv_ls2[l];
-                    close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
-                }
-            }
-            double k0, k1, k2;
-            kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
-            ck[a * (CH + 1) + k] = valid ? (pv[a] * al - 2.0 * wv) * var2 * k1 : 0.0;
-            if (valid && close) flag = 1;
+            const double wv = Wrows[(size_t)a * npad + kg], kv = Krows[(size_t)a * npad + kg];
+            ck[a * (CH + 1) + k] = (kg < n) ? (pv[a] * al - 2.0 * wv) * kv : 0.0;
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < ITEMS_MAX; ++u) {
-            if (u * T >= nitems) break;                  // uniform; idle lanes redo item 0
-            const int e = (tid + u * T < nitems) ? tid + u * T : 0;
+        for (int e = tid; e < nitems; e += T) {
             const int a = e / dp, l = e - a * dp;
             const lds_f64* ca = ck + a * (CH + 1);
             const lds_f64* xl = Xc + l;
             double s0 = 0.0, s1 = 0.0;
-#pragma unroll 4
-            for (int kk = 0; kk < CH; kk += 2) {
-                s0 += ca[kk] * xl[kk * dl];
-                s1 += ca[kk + 1] * xl[(kk + 1) * dl];
+#pragma unroll 2
+            for (int k0 = 0; k0 < CH; k0 += 8) {         // 16 LDS reads in flight, then 8 multiply-adds
+                double av[8], bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { av[j] = ca[k0 + j]; bv[j] = xl[(k0 + j) * dl]; }
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) { s0 += av[j] * bv[j]; s1 += av[j + 1] * bv[j + 1]; }
+                SDP_READS_FIRST(16, 8);
             }
-            acc[u] += s0 + s1;
+            Gl[e] += s0 + s1;                            // this thread's own accumulator
         }
     }
     // self-covariance derivative factors and mutual-duplicate test (oei.py:190)
@@ -315,14 +305,7 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
         if (a != bb && same) flag = 1;
     }
     __syncthreads();
-    lds_f64* Gacc = ck;     // reuse: [q][dp]
-#pragma unroll
-    for (int u = 0; u < ITEMS_MAX; ++u) {
-        const int e = tid + u * T;
-        if (e >= nitems) break;
-        Gacc[e] = acc[u];
-    }
-    __syncthreads();
+    const lds_f64* Gacc = Gl;
     for (int e = tid; e < q * d; e += T) {
         const int a = e / d, l = e - a * d;
         double gval = (xq[a * d + l] * Gacc[a * dp + d] - Gacc[a * dp + l]) * kp.inv_ls2[l];
@@ -334,7 +317,7 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
     }
     if (flags) {
         flag = __syncthreads_or(flag);
-        if (tid == 0) flags[b] = flag;
+        if (tid == 0 && flag) flags[b] = 1;          // zeroed by the caller; the Gram kernel may have set it
     }
 }
 
@@ -403,7 +386,7 @@ static int cross_factor(oei_model* m, const double* Xq, size_t rows, size_t aux_
     const size_t rows_pad = round_up(rows, 64);
     int rc = oei_ws_reserve(m, rows_pad, aux_bytes);
     if (rc) return rc;
-    rc = oei_launch_gram(m, Xq, rows, rows_pad, m->ws0, st);
+    rc = oei_launch_gram(m, Xq, rows, rows_pad, m->ws0, nullptr, 1, nullptr, st);
     if (rc) return rc;
     return oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows_pad, m->npad, 1, st);
 }
@@ -483,7 +466,9 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     rc = oei_ws_reserve(m, rows_pad, aux_bytes);
     if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[0], st));
-    rc = oei_launch_gram(m, X, rows, rows_pad, m->ws0, st);
+    if ((rc = oei_ws2_reserve(m, rows_pad))) return rc;
+    if (flags) OEI_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
+    rc = oei_launch_gram(m, X, rows, rows_pad, m->ws0, m->ws2, q, flags, st);   // ws0 = Ks, ws2 = K1
     if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[1], st));
     rc = oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows_pad, m->npad, 1, st);   // ws1 = A
@@ -491,8 +476,8 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[2], st));
     double* p_buf = m->aux;
     double* M11_buf = m->aux + (size_t)B * q;
-    const size_t ldsg = ((size_t)q * d + 2 * (size_t)q * q + q + (size_t)q * (CH + 1) + (size_t)CH * ((d + 1) | 1)) * sizeof(double);
-    if (q * (d + 1) > ITEMS_MAX * (q <= 32 ? 64 : 256) || q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
+    const size_t ldsg = ((size_t)q * d + 2 * (size_t)q * q + q + (size_t)q * (CH + 1) + (size_t)CH * ((d + 1) | 1) + (size_t)q * (d + 1)) * sizeof(double);
+    if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
         return OEI_ERR_ARG;
     }
@@ -505,16 +490,11 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
     if (q <= 32) {
-        if (d == 6) {
-            if ((rc = set_lds(k_grad<64, 6>, ldsg))) return rc;
-            hipLaunchKernelGGL((k_grad<64, 6>), dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
-        } else {
-            if ((rc = set_lds(k_grad<64, 0>, ldsg))) return rc;
-            hipLaunchKernelGGL((k_grad<64, 0>), dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
-        }
+        if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
+        hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
     } else {
-        if ((rc = set_lds(k_grad<256, 0>, ldsg))) return rc;
-        hipLaunchKernelGGL((k_grad<256, 0>), dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, p_buf, M11_buf, grad, flags);
+        if ((rc = set_lds(k_grad<256>, ldsg))) return rc;
+        hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
     }
     OEI_HIP_CHECK(hipGetLastError());
     if (prof) { OEI_HIP_CHECK(hipEventRecord(m->ev[5], st)); m->ev_valid = 1; }

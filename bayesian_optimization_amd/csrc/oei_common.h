@@ -49,6 +49,8 @@ struct oei_model {
     size_t ws_rows;   // rows currently allocated in each of ws0/ws1
     double* ws0;      // [rows, npad]
     double* ws1;      // [rows, npad]
+    size_t ws2_rows;  // rows allocated in ws2
+    double* ws2;      // [rows, npad]: kernel-derivative factors kept for the gradient
     size_t aux_bytes;
     double* aux;      // per-candidate state (p, M11, ...)
     size_t hs_bytes;  // Hessian-path scratch (Gram blocks, Z/W rows)
@@ -101,8 +103,11 @@ int oei_ws_reserve(oei_model* m, size_t rows, size_t aux_bytes);
 
 // Ks[r, k] = k(x_r, X_k) for r < rows (x_r = row r of Xq [rows, d]); zero for r >= rows or k >= n.
 // MODE 0: kernel value; MODE 1..d: derivative of k(x_r, X_k) with respect to x_r[MODE-1].
+// K1 (optional): 2 var kappa'(t) of the same pairs, the factor the gradient needs; with it, `q`
+// and `flags`: flags[r / q] is raised when x_r duplicates a training point (oei.py:165-167).
 int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
-                    double* Ks, hipStream_t st);
+                    double* Ks, double* K1, int q, int* flags, hipStream_t st);
+int oei_ws2_reserve(oei_model* m, size_t rows);
 // Extended rows of the Hessian path: per candidate RP rows (value rows, derivative rows, y, zeros).
 int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int RP, double* out,
                         hipStream_t st);

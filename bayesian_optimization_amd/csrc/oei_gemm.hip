@@ -25,9 +25,12 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // once per block; stores are coalesced along k.
 #define GR_ROWS 32
 
+template <bool WITH_K1>
 __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __restrict__ Xtrain,
                                               int n, int npad, const double* __restrict__ Xq,
-                                              size_t rows, double* __restrict__ out) {
+                                              size_t rows, double* __restrict__ out,
+                                              double* __restrict__ out1, int q,
+                                              int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int d = kp.d;
     double* Xs = sm;                 // [64][d]
@@ -49,21 +52,31 @@ __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __res
     for (int rr = tid >> 6; rr < GR_ROWS; rr += 4) {
         const size_t r = r0 + rr;
         double t = 0.0;
+        bool close = true;
         for (int l = 0; l < d; ++l) {
             double df = Qs[rr * d + l] - Xs[kk * d + l];
             t += df * df * kp.inv_ls2[l];
+            if (WITH_K1) close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
         }
         double k0v, k1v, k2v;
-        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
-        out[r * npad + k] = ((r < rows) && (k < n)) ? kp.variance * k0v : 0.0;
+        kappa_eval<WITH_K1 ? 1 : 0>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
+        const bool in = (r < rows) && (k < n);
+        out[r * npad + k] = in ? kp.variance * k0v : 0.0;
+        if (WITH_K1) {
+            out1[r * npad + k] = in ? 2.0 * kp.variance * k1v : 0.0;
+            if (in && close && flags) flags[r / q] = 1;      // every writer stores the same value
+        }
     }
 }
 
 int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
-                    double* Ks, hipStream_t st) {
+                    double* Ks, double* K1, int q, int* flags, hipStream_t st) {
     dim3 grid((unsigned)(rows_pad / GR_ROWS), m->npad / 64);
     size_t lds = (size_t)(64 + GR_ROWS) * m->d * sizeof(double);
-    hipLaunchKernelGGL(k_gram, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks);
+    if (K1)
+        hipLaunchKernelGGL(k_gram<true>, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, K1, q, flags);
+    else
+        hipLaunchKernelGGL(k_gram<false>, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, (double*)nullptr, 1, (int*)nullptr);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

@@ -246,7 +246,7 @@ static void model_free(oei_model* m) {
     if (!m) return;
     hipFree(m->X); hipFree(m->L); hipFree(m->Linv); hipFree(m->LinvT);
     hipFree(m->v); hipFree(m->alpha); hipFree(m->y);
-    hipFree(m->ws0); hipFree(m->ws1); hipFree(m->aux); hipFree(m->hs);
+    hipFree(m->ws0); hipFree(m->ws1); hipFree(m->ws2); hipFree(m->aux); hipFree(m->hs);
     if (m->ev[0]) for (int i = 0; i < 6; ++i) hipEventDestroy(m->ev[i]);
     delete m;
 }
@@ -348,6 +348,16 @@ extern "C" int oei_model_get_factor(const oei_model* m, double* L_host) {
     if (!m || !L_host) { oei_set_error("model_get_factor: null pointer"); return OEI_ERR_ARG; }
     OEI_HIP_CHECK(hipMemcpy2D(L_host, (size_t)m->n * sizeof(double), m->L, (size_t)m->npad * sizeof(double),
                               (size_t)m->n * sizeof(double), m->n, hipMemcpyDeviceToHost));
+    return OEI_OK;
+}
+
+int oei_ws2_reserve(oei_model* m, size_t rows) {
+    if (rows > m->ws2_rows) {
+        if (m->ws2) OEI_HIP_CHECK(hipFree(m->ws2));
+        m->ws2 = nullptr; m->ws2_rows = 0;
+        OEI_HIP_CHECK(hipMalloc(&m->ws2, rows * (size_t)m->npad * sizeof(double)));
+        m->ws2_rows = rows;
+    }
     return OEI_OK;
 }
 
