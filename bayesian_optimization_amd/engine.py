@@ -90,6 +90,18 @@ class DeviceGP:
         return [float(x) for x in ms]
 
     # ---- batched device API -----------------------------------------------------------------
+    def nlml(self, want_grad=True, ard=False):
+        """Negative log marginal likelihood of the model and its gradient with respect to
+        (variance, lengthscale(s), noise): the objective of the hyper-parameter fit
+        (bo.py:194-221).  Returns (value, grad numpy [2 + nls]) with nls = d if `ard` else 1."""
+        import ctypes
+        nls = self.dim if ard else 1
+        value = ctypes.c_double(0.0)
+        grad = (ctypes.c_double * (2 + nls))() if want_grad else None
+        with torch.cuda.device(self.device):
+            check(lib.oei_model_nlml(self._h, ctypes.byref(value), grad, nls), 'oei_model_nlml')
+        return value.value, (np.array(grad[:]) if want_grad else None)
+
     def predict_f(self, X):
         X = _dev_f64(X, self.device).reshape(-1, self.dim)
         m = X.shape[0]

@@ -1,0 +1,90 @@
+"""Maximum-likelihood (or MAP) fit of the GP hyper-parameters with random restarts.
+
+The reference does this step with gpflow before every batch: `BO.optimize_restarts`
+(bo.py:194-221) keeps the best of `model_restarts` runs of gpflow's `optimize()` (scipy L-BFGS-B
+on the negative log marginal likelihood, plus log-priors when `--priors 1`: Gamma(2, 0.5) on the
+lengthscales and Gaussian(1, 2) on the kernel variance, run.py:95-97), each started from a random
+draw of the free parameters.  Here the objective and its gradient come from the device
+(`oei_model_nlml`: Cholesky, triangular inverse and the trace terms run on the GPU); the outer
+optimiser is the same scipy L-BFGS-B.  Parameters are optimised through theta = log(parameter)
+(gpflow uses a softplus transform; both keep the parameters positive, restarts are drawn as
+theta ~ N(0, 1) around zero as gpflow's `randomize()` does in its free space).
+"""
+import numpy as np
+import scipy.optimize
+
+from . import _lib
+from .engine import DeviceGP
+
+
+def _neg_log_prior(variance, ls, priors):
+    """-(log Gamma(ls; shape 2, scale 0.5) + log N(variance; 1, 2)) and derivatives."""
+    if not priors:
+        return 0.0, 0.0, np.zeros_like(ls)
+    shape, scale = 2.0, 0.5
+    val = -np.sum((shape - 1.0) * np.log(ls) - ls / scale)
+    dls = -((shape - 1.0) / ls - 1.0 / scale)
+    val += 0.5 * (variance - 1.0) ** 2 / 2.0
+    dvar = (variance - 1.0) / 2.0
+    return val, dvar, dls
+
+
+def objective(theta, X, y, kind, floor_mode, ard, fixed_noise, priors, device=None):
+    """theta = log([variance, lengthscale(s), noise]) (noise absent when fixed).  Returns
+    (value, gradient with respect to theta); +inf when the covariance is not positive definite."""
+    d = X.shape[1]
+    nls = d if ard else 1
+    variance = float(np.exp(theta[0]))
+    ls = np.exp(theta[1:1 + nls])
+    noise = float(fixed_noise) if fixed_noise is not None else float(np.exp(theta[1 + nls]))
+    try:
+        gp = DeviceGP(X, y, kind, variance, ls, noise, floor_mode=floor_mode, device=device)
+    except _lib.OeiError:
+        return np.inf, np.zeros_like(theta)
+    try:
+        value, grad = gp.nlml(want_grad=True, ard=ard)
+    finally:
+        gp.close()
+    pv, dvar, dls = _neg_log_prior(variance, ls, priors)
+    value += pv
+    g = np.empty_like(theta)
+    g[0] = (grad[0] + dvar) * variance
+    g[1:1 + nls] = (grad[1:1 + nls] + dls) * ls
+    if fixed_noise is None:
+        g[1 + nls] = grad[1 + nls] * noise
+    if not np.isfinite(value):
+        return np.inf, np.zeros_like(theta)
+    return float(value), g
+
+
+def fit(X, y, kind, variance, lengthscales, noise, floor_mode=None, ard=False, fixed_noise=True,
+        priors=False, restarts=1, rng=np.random, device=None, maxiter=1000):
+    """Best of `restarts` L-BFGS-B runs (plus the current parameters as a candidate, as
+    bo.py:204-219 does).  Returns dict(variance, lengthscales, noise, nlml)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+    d = X.shape[1]
+    nls = d if ard else 1
+    ls0 = np.broadcast_to(np.asarray(lengthscales, dtype=np.float64).reshape(-1), (nls,)) if ard \
+        else np.asarray(lengthscales, dtype=np.float64).reshape(-1)[:1]
+    fn = float(noise) if fixed_noise else None
+    theta0 = np.log(np.concatenate([[variance], ls0] + ([] if fixed_noise else [[max(noise, 1e-12)]])))
+
+    def f(th):
+        return objective(th, X, y, kind, floor_mode, ard, fn, priors, device)
+    best_theta, best_val = theta0, f(theta0)[0]
+    for _ in range(int(restarts)):
+        start = rng.randn(theta0.size)
+        try:
+            res = scipy.optimize.minimize(f, start, jac=True, method='L-BFGS-B',
+                                          bounds=[(-12.0, 8.0)] * theta0.size, options={'maxiter': maxiter})
+            val, th = float(res.fun), res.x
+        except KeyboardInterrupt:
+            raise
+        except Exception:
+            val, th = np.inf, start
+        if val < best_val:
+            best_theta, best_val = th, val
+    out_noise = float(noise) if fixed_noise else float(np.exp(best_theta[1 + nls]))
+    return dict(variance=float(np.exp(best_theta[0])), lengthscales=np.exp(best_theta[1:1 + nls]),
+                noise=out_noise, nlml=float(best_val))

@@ -159,10 +159,26 @@ class BO(object):
         return best[2].cpu().numpy()
 
     def optimize_restarts(self, restarts=1, **kwargs):
-        """Hyper-parameter fit of bo.py:194-221.  The reference maximises the GP marginal likelihood
-        with gpflow; that step precedes the hot path and is not part of it.  Hyper-parameters stay
-        at their current values here unless a subclass overrides this."""
-        return None
+        """Hyper-parameter fit of bo.py:194-221: best of `restarts` maximum-likelihood runs (MAP
+        with `options['priors']`), objective and gradient evaluated on the GPU (hyperfit.py).
+        The fit runs when `options['fit_hyperparameters']` is set (the driver sets it); without
+        it the hyper-parameters stay at their current values."""
+        if not self.options.get('fit_hyperparameters') or restarts is None:
+            return None
+        from .. import hyperfit
+        res = hyperfit.fit(self.X.value, self.Y.value[:, 0], self.kern.kind,
+                           float(self.kern.variance.value), np.atleast_1d(self.kern.lengthscales.value),
+                           float(self.likelihood.variance.value), floor_mode=self.kern.floor_mode,
+                           ard=self.kern.ARD, fixed_noise=self.likelihood.variance.fixed,
+                           priors=bool(self.options.get('priors')), restarts=restarts)
+        self.kern.variance = Param(res['variance'])
+        self.kern.lengthscales = Param(res['lengthscales'] if self.kern.ARD else res['lengthscales'][0])
+        if not self.likelihood.variance.fixed:
+            self.likelihood.variance = Param(res['noise'])
+        self._gp = None
+        logging.getLogger('model').info('variance %.6g lengthscales %s noise %.6g nlml %.6f'
+                                        % (res['variance'], res['lengthscales'], res['noise'], res['nlml']))
+        return res
 
     @staticmethod
     def random_sample(bounds, k):

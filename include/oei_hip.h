@@ -116,6 +116,13 @@ int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* dome
 int oei_set_profiling(oei_model* m, int on);
 int oei_get_stage_times(oei_model* m, float* ms5);
 
+/* ---- hyper-parameter objective ------------------------------------------------------------------
+ * Negative log marginal likelihood of the GP behind the handle and its gradient, the objective of
+ * the reference's hyper-parameter fit (gpflow's optimize() called from BO.optimize_restarts,
+ * bo.py:85,194-221).  value: host double[1].  grad (host, may be NULL):
+ * [d/d variance, d/d lengthscale (n_lengthscales entries: 1 shared or d ARD), d/d noise]. */
+int oei_model_nlml(oei_model* m, double* value, double* grad, int n_lengthscales);
+
 /* ---- multistart selection ----------------------------------------------------------------------
  * Local half of "keep the best start" (bo.py:158-161): arg-min over value[0..B) with ties to the
  * lowest index.  Writes best_value (device double[1]) and best_index (device long long[1], offset
