@@ -48,6 +48,13 @@ def _load():
         raise ImportError(
             'liboei_hip.so not found at %s: build it with `make -C %s` (hipcc, gfx950). '
             'There is no CPU fallback.' % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    # torch (which owns device memory and streams for this package) must have brought up its HIP
+    # runtime before this library's code objects register: loaded in the other order, the
+    # library's first runtime call reports that no device is present.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+        torch.empty(1, device='cuda')
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
