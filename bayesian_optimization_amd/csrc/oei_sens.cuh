@@ -53,26 +53,45 @@ __device__ int sens_prepare(const SdpWork w, const lds_f64* mu, const SensVec sv
         for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * w.rp[a];
         sv.c[tid] = mu[tid] + acc;
         sv.t1[tid] = w.sq[tid] * w.rp[tid];
+        w.rc[tid] = 1.0 / w.H[tid * LD + tid];           // for the per-direction triangular solves
     }
     __syncthreads();
     return 0;
 }
 
-// C[i][j] = sum_k A[i][k] * B[k][j]  (TA: use A[k][i]; TB: use B[j][k])
-template <int T, bool TA, bool TB>
-__device__ __forceinline__ void lds_mm(int q, int LD, const lds_f64* A, const lds_f64* B, lds_f64* C) {
+// C[i][j] = sum_k A[i][k] * B[k][j] * sc[k]  (TA: use A[k][i]; TB: use B[j][k]; SC: with the
+// scale vector, else without).  Eight terms at a time: the LDS reads of a group are issued before
+// its multiply-adds so that the read latency is paid once per group, not once per term.
+template <int T, bool TA, bool TB, bool SC = false>
+__device__ __forceinline__ void lds_mm(int q, int LD, const lds_f64* A, const lds_f64* B, lds_f64* C,
+                                       const lds_f64* sc = nullptr) {
     for (int e = threadIdx.x; e < q * q; e += T) {
         const int i = e / q, j = e - i * q;
-        double acc = 0.0;
-#pragma unroll 4
-        for (int k = 0; k < q; ++k)
-            acc += (TA ? A[k * LD + i] : A[i * LD + k]) * (TB ? B[j * LD + k] : B[k * LD + j]);
-        C[i * LD + j] = acc;
+        const lds_f64* ap = TA ? A + i : A + i * LD;
+        const lds_f64* bp = TB ? B + j * LD : B + j;
+        const int sa = TA ? LD : 1, sb = TB ? 1 : LD;
+        double acc0 = 0.0, acc1 = 0.0;
+        int k = 0;
+        for (; k + 8 <= q; k += 8) {
+            double av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = ap[(k + u) * sa];
+                bv[u] = bp[(k + u) * sb];
+                if (SC) av[u] *= sc[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { acc0 += av[u] * bv[u]; acc1 += av[u + 1] * bv[u + 1]; }
+            SDP_READS_FIRST(24, 16);
+        }
+        for (; k < q; ++k) acc0 += ap[k * sa] * bp[k * sb] * (SC ? sc[k] : 1.0);
+        C[i * LD + j] = acc0 + acc1;
     }
 }
 
 // One direction.  In: sv.dmu, dS (symmetric) in w.X.  Out: dN in w.X, sv.w1 = N dc, sv.w2 = dN c,
 // sv.dp, Z in w.Kt; returns dnu.  dM11 = -dN, dM[:q,q] = w1 + w2, dM[q][q] = -dnu.
+// Needs w.rc = 1 / diag(L) of the factor in w.H (sens_prepare).
 template <int T>
 __device__ double sens_direction(const SdpWork w, const SensVec sv) {
     const int tid = threadIdx.x;
@@ -88,56 +107,77 @@ __device__ double sens_direction(const SdpWork w, const SensVec sv) {
     __syncthreads();
     for (int e = tid; e < q * q; e += T) {                // ZS
         const int a = e / q, b = e - a * q;
-        Tc[a * LD + b] *= -0.5 / (w.sq[a] * w.sq[b] * (w.sq[a] + w.sq[b]));
+        const double sa = w.sq[a], sb = w.sq[b];
+        Tc[a * LD + b] *= -0.5 * sdp_rcp(sa * sb * (sa + sb));
     }
     __syncthreads();
+    // rhs = dmu - (dBS_ii - 2 (dBS p)_i)/4 with dBS = -4 Rs ZS Rs^T, Rs = R diag(sq):
+    // M1 = ZS Rs^T (into Tb), t2 = ZS t1, rhs_i = dmu_i + sum_a Rs[i][a] (M1[a][i] - 2 t2[a])
+    lds_mm<T, false, true, true>(q, LD, Tc, w.R, Tb, w.sq);
     if (tid < q) {
         double acc = 0.0;
         for (int b = 0; b < q; ++b) acc += Tc[tid * LD + b] * sv.t1[b];
         sv.t2[tid] = acc;
     }
     __syncthreads();
-    if (tid < q) {        // rhs = dmu - (dBS_ii - 2 (dBS p)_i)/4,  dBS = -4 Rs ZS Rs^T
-        const int i = tid;
-        double dii = 0.0, dp_ = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double ra = w.R[i * LD + a] * w.sq[a];
-            double inner = 0.0;
-            for (int b = 0; b < q; ++b) inner += Tc[a * LD + b] * w.R[i * LD + b] * w.sq[b];
-            dii += ra * inner;
-            dp_ += ra * sv.t2[a];
+    double rhs = 0.0;
+    if (tid < q) {
+        double acc = 0.0;
+#pragma unroll 4
+        for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * (Tb[a * LD + tid] - 2.0 * sv.t2[a]);
+        rhs = sv.dmu[tid] + acc;
+    }
+    // A x = rhs with A = L L^T = -hess g
+    if constexpr (T == 64) {
+        // one wave: the running vector stays in a register, solved components are broadcast
+        // through the scalar unit; L is read from LDS (reads do not depend on the chain)
+        const int row = tid < q ? tid : 0;
+        const double dinv = w.rc[row];
+        double bv = rhs;
+#pragma unroll 4
+        for (int k = 0; k < q; ++k) {
+            const double lk = w.H[row * LD + k];
+            const double yk = sdp_lane_bcast(bv * dinv, k);
+            bv = (tid == k) ? yk : (tid > k ? bv - lk * yk : bv);
         }
-        w.step[i] = sv.dmu[i] + dii - 2.0 * dp_;
+#pragma unroll 4
+        for (int k = q - 1; k >= 0; --k) {
+            const double lk = w.H[k * LD + row];
+            const double xk = sdp_lane_bcast(bv * dinv, k);
+            bv = (tid == k) ? xk : (tid < k ? bv - lk * xk : bv);
+        }
+        if (tid < q) sv.dp[tid] = -bv;
+    } else {
+        if (tid < q) w.step[tid] = rhs;
+        __syncthreads();
+        for (int k = 0; k < q; ++k) {
+            const double yk = w.step[k] * w.rc[k];
+            __syncthreads();
+            if (tid == k) w.step[k] = yk;
+            if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
+            __syncthreads();
+        }
+        for (int k = q - 1; k >= 0; --k) {
+            const double xk = w.step[k] * w.rc[k];
+            __syncthreads();
+            if (tid == k) w.step[k] = xk;
+            if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
+            __syncthreads();
+        }
+        if (tid < q) sv.dp[tid] = -w.step[tid];
     }
-    __syncthreads();
-    for (int k = 0; k < q; ++k) {          // A x = rhs with A = L L^T = -hess g
-        const double yk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = yk;
-        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
-        __syncthreads();
-    }
-    for (int k = q - 1; k >= 0; --k) {
-        const double xk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = xk;
-        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
-        __syncthreads();
-    }
-    if (tid < q) sv.dp[tid] = -w.step[tid];
     __syncthreads();
     if (tid < q) {
         double acc = 0.0;
         for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * sv.dp[i];
         sv.rd[tid] = acc;
     }
+    lds_mm<T, true, false, true>(q, LD, w.R, w.R, Tb, sv.dp);   // Tb = R^T diag(dp) R
     __syncthreads();
     for (int e = tid; e < q * q; e += T) {                // Z = ZS + Phi o (R^T dD R)/4
         const int a = e / q, b = e - a * q;
-        double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc += sv.dp[i] * w.R[i * LD + a] * w.R[i * LD + b];
-        acc -= sv.rd[a] * w.rp[b] + w.rp[a] * sv.rd[b];
-        Tc[a * LD + b] += 0.5 * acc / (w.sq[a] + w.sq[b]);
+        const double acc = Tb[a * LD + b] - sv.rd[a] * w.rp[b] - w.rp[a] * sv.rd[b];
+        Tc[a * LD + b] += 0.5 * acc * sdp_rcp(w.sq[a] + w.sq[b]);
     }
     __syncthreads();
     lds_mm<T, false, true>(q, LD, Tc, U, Tb);             // Tb = Z U^T
