@@ -35,9 +35,11 @@ def select_best(rec, group=None):
     Without an initialised process group the local record wins."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
-        flat = torch.empty(world * rec.numel(), dtype=rec.dtype, device=rec.device)
-        dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)
-        allrec = flat.reshape(world, rec.numel())
+        # RCCL gathers device tensors in place; gloo (CPU tests, one-GPU rehearsals) gets host copies
+        src = rec.contiguous() if dist.get_backend(group) != 'gloo' else rec.detach().cpu().contiguous()
+        flat = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(flat, src, group=group)
+        allrec = flat.reshape(world, rec.numel()).to(rec.device)
     else:
         allrec = rec.reshape(1, -1)
     values = allrec[:, 0]
