@@ -36,6 +36,16 @@ def setup_logging(job_name, seed):
         logger.addHandler(handler)
 
 
+def teardown_logging():
+    """Closes the run's log files and gives the three loggers back their default behaviour."""
+    for name in ('evals', 'model', 'opt'):
+        logger = logging.getLogger(name)
+        for h in list(logger.handlers):
+            logger.removeHandler(h)
+            h.close()
+        logger.propagate = True
+
+
 def run(options, seed, robust=False, save=False):
     from .methods.oei import OEI
     options = dict(options)
@@ -56,7 +66,9 @@ def run(options, seed, robust=False, save=False):
         print('Experiment of', bo.options['job_name'], 'with seed', seed, 'failed')
         X, Y = None, None
         if not robust:
+            teardown_logging()
             raise
+    teardown_logging()
     if save:
         folder = os.path.join('out', bo.options['job_name'])
         os.makedirs(folder, exist_ok=True)
