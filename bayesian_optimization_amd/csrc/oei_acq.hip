@@ -49,7 +49,7 @@ __device__ __forceinline__ void posterior_moments(const SdpWork w, const KernPar
     auto fetch = [&](int c) {
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
-            if (u * T < q * CH) {                        // uniform
+            if (tid + u * T < q * CH) {                  // the last group is partial when q * CH % T != 0
                 const int e = tid + u * T, a = e / CH, k = e - a * CH;
                 nxt[u] = Arows[(size_t)a * astride + c * CH + k];
             }
@@ -61,7 +61,7 @@ __device__ __forceinline__ void posterior_moments(const SdpWork w, const KernPar
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < NE; ++u) {
-            if (u * T < q * CH) {
+            if (tid + u * T < q * CH) {
                 const int e = tid + u * T, a = e / CH, k = e - a * CH;
                 Ac[a * (CH + 1) + k] = nxt[u];
             }

@@ -144,3 +144,18 @@ def test_sdp_batched_mixed_conditioning(cuda):
         for b in range(len(fms)):
             cert = sdp_ref.kkt_certificate(oms[b], fms[b], M[b], list(Y[b]))
             assert max(v for kk, v in cert.items() if kk not in ('pobj', 'dobj')) < 1e-7, (k, b, cert)
+
+
+@pytest.mark.parametrize('q,B', [(33, 64), (50, 32), (20, 16)])
+def test_rows_fill_the_workspace_exactly(cuda, q, B):
+    """B * q a multiple of the 64-row padding: the last candidate's rows end where the workspace
+    ends, so any read or staging write past a candidate's own rows would leave the allocation.
+    Results must equal those of the same candidates evaluated in a batch with slack."""
+    om, dm = _mk(60)
+    assert (B * q) % 64 == 0
+    Xs = np.random.RandomState(61).uniform(-.5, .5, (B, q, 6))
+    v, g, st, _ = dm.value_grad(Xs)
+    assert (st.cpu().numpy() == 0).all()
+    v2, g2, st2, _ = dm.value_grad(Xs[-3:])
+    assert torch.equal(v[-3:], v2) and torch.equal(g[-3:], g2)
+    _check_batch(om, dm, Xs[-2:])

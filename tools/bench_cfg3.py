@@ -1,0 +1,20 @@
+"""Diagnostic: value+gradient throughput at the largest configuration (n=1000, q=50, d=10)."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.')
+from oracle import hart6, gp as ogp
+from bayesian_optimization_amd import DeviceGP
+
+model = hart6.make_model(1000, d=10, lengthscale=0.8)
+gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.8], 1e-6, floor_mode=1)
+gp.set_profiling(True)
+for B in (64, 512, 2048):
+    X = torch.as_tensor(np.random.RandomState(2).uniform(-.5, .5, (B, 50, 10)), device='cuda')
+    gp.value_grad(X); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        v, g, st, fl = gp.value_grad(X)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print('B=%5d  %.2f ms  %.0f evals/s  unsolved %d  stages %s' % (B, dt * 1e3, B / dt, int((st != 0).sum()),
+          np.round(gp.stage_times_ms(), 2)))
