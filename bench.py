@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Benchmark of the OEI value+gradient path (BASELINE.json metric).
+"""Benchmark of the OEI value+gradient path: candidate evaluations per second.
 
     python bench.py --gpus N --steps K --warmup W
 

@@ -1,4 +1,4 @@
-"""Diagnostic: throughput of oei_hessian_batched at q = 20, n = 310 (SURVEY cfg 1 shape)."""
+"""Diagnostic: throughput of oei_hessian_batched at q = 20, n = 310."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
