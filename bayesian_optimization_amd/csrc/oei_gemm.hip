@@ -208,11 +208,19 @@ __device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
 
 __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
                                                  const double* __restrict__ Bm,
-                                                 double* __restrict__ C, int npad, int lower) {
+                                                 double* __restrict__ C, int npad, int lower,
+                                                 unsigned nrb) {
     __shared__ __attribute__((aligned(16))) double As[2 * GM_BM * GM_LDS];
     __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
-    const int j0 = blockIdx.y * GM_BN;
-    const size_t r0 = (size_t)blockIdx.x * GM_BM;
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own
+    // L2.  The nt column tiles of one 64-row panel of A are therefore given consecutive slots of
+    // the SAME XCD, so that the panel is fetched from HBM once and re-read from that L2.
+    const int nt = npad / GM_BN;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const size_t rb = (size_t)(slot / nt) * 8 + xcd;
+    if (rb >= nrb) return;
+    const int j0 = (int)(slot % nt) * GM_BN;
+    const size_t r0 = rb * GM_BM;
     const int kbeg = lower ? 0 : j0;
     const int kend = lower ? (j0 + GM_BN) : npad;
     gemm_tile_nt(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
@@ -224,8 +232,9 @@ int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows
         oei_set_error("gemm_nt: rows_pad=%zu / npad=%d not tile multiples", rows_pad, npad);
         return OEI_ERR_ARG;
     }
-    dim3 grid((unsigned)(rows_pad / GM_BM), npad / GM_BN);
-    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, A, Bm, C, npad, lower);
+    const unsigned nrb = (unsigned)(rows_pad / GM_BM), nt = (unsigned)(npad / GM_BN);
+    dim3 grid(((nrb + 7) / 8) * 8 * nt);
+    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, A, Bm, C, npad, lower, nrb);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }
