@@ -25,10 +25,11 @@
 //
 // Two implementations:
 //   * register path (q <= Q <= 32, one 64-lane wave, template parameter Q > 0): one-sided
-//     (Hestenes) Jacobi with lane j holding column j of G in registers; the pairs of a round
-//     exchange columns with wave shuffles, no LDS traffic and no eigenvector accumulation (U
-//     follows from a triangular solve with Lc).  The previous U seeds the next evaluation
-//     (G <- G V_prev), which saves sweeps as the Newton steps shrink.  Everything the Newton step
+//     (Hestenes) Jacobi with the columns of G in registers (column j spread over the 64/Q lanes
+//     j, j+Q, ...); the pairs of a round exchange columns with wave shuffles, no LDS traffic and
+//     no eigenvector accumulation (U follows from a triangular solve with Lc).  The previous U
+//     seeds the next evaluation (G <- G V_prev), which saves sweeps as the Newton steps shrink.
+//     Everything the Newton step
 //     needs is expressed through U, so three q x q matrices of LDS suffice (Lc, U and one that
 //     holds the Hessian in its lower and the Loewner kernel in its upper triangle): the small
 //     footprint is what lets ten and more candidates share a compute unit.
@@ -411,64 +412,6 @@ __device__ int sdp_newton_dir_lds(const SdpWork w) {
 // Register path (one 64-lane wave, q <= Q <= 32).  EXACT: q == Q, the unrolled loops carry no
 // bounds tests, LD is a constant and the code is straight-line.
 // ================================================================================================
-// One-sided Jacobi: lane j owns column j of G.  Pairs of a round exchange columns with wave
-// shuffles; a rotation needs alpha = |g_i|^2, beta = |g_j|^2, gamma = g_i . g_j only.  The squared
-// norms are carried along (alpha_i -= t gamma, alpha_j += t gamma) and recomputed once per sweep.
-// Q is the padded size (even); columns >= q are zero and never rotate.  Returns the sweep count.
-template <int Q>
-__device__ int sdp_jacobi_reg(double (&g)[Q], double tol2, double fin2) {
-    const int lane = threadIdx.x & 63;
-    int sweep = 0;
-    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
-        bool rotated = false;
-        double alpha = 0.0;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) alpha += g[k] * g[k];
-        // round-robin pairing: lanes < Q-1 meet (2r - lane) mod (Q-1), the fixed point of that map
-        // meets lane Q-1; `base` follows (2r - lane) mod (Q-1) incrementally
-        int base = (lane < Q - 1) ? ((Q - 1 - lane) % (Q - 1)) : 0;
-        for (int r = 0; r < Q - 1; ++r) {
-            int partner = lane;
-            if (lane < Q - 1) partner = (base == lane) ? Q - 1 : base;
-            else if (lane == Q - 1) partner = r;
-            base += 2;
-            if (base >= Q - 1) base -= Q - 1;
-            double pg[Q];
-#pragma unroll
-            for (int k = 0; k < Q; ++k) pg[k] = __shfl(g[k], partner, 64);
-            const double beta = __shfl(alpha, partner, 64);
-            double gm0 = 0.0, gm1 = 0.0;
-#pragma unroll
-            for (int k = 0; k < Q; k += 2) { gm0 += g[k] * pg[k]; gm1 += g[k + 1] * pg[k + 1]; }
-            const double gamma = gm0 + gm1;
-            const bool low = lane < partner;
-            double c = 1.0, sg = 0.0;
-            const double g2 = gamma * gamma, aa = alpha * beta;
-            const bool rot = (lane < Q) && (partner != lane) &&
-                             (g2 > tol2 * aa);
-            if (rot) {
-                // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = alpha_j - alpha_i  (i < j)
-                const double d = low ? beta - alpha : alpha - beta;
-                const double x = fma(d, d, 4.0 * g2);
-                const double h = x * sdp_rsq(x);
-                double t = 2.0 * gamma * sdp_rcp(fabs(d) + h);
-                if (d < 0.0) t = -t;
-                c = sdp_rsq(fma(t, t, 1.0));
-                const double ts = low ? -t : t;
-                sg = ts * c;                     // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
-                alpha = fma(ts, gamma, alpha);
-            }
-            // the iteration converges quadratically: once every rotation of a sweep had
-            // |gamma| <= 1e-7 sqrt(alpha beta), what is left afterwards is below the tolerance
-            rotated |= rot && (g2 > fin2 * aa);
-#pragma unroll
-            for (int k = 0; k < Q; ++k) g[k] = c * g[k] + sg * pg[k];
-        }
-        if (!__any(rotated)) { ++sweep; break; }
-    }
-    return sweep;
-}
-
 // Cholesky A = L L^T inside one wave: lane i keeps row i (a[k], k <= i, zeros behind) in
 // registers, pivots and multipliers travel through the scalar unit.  On return a[] holds row i of
 // L and dinv = 1/L_ii.  Returns 1 if a pivot is not positive (the arithmetic carries on).
