@@ -1,0 +1,14 @@
+#!/bin/bash
+# Collects what profiles/ is made from: bench line, rocprofv3 kernel statistics, and the two HBM
+# counter passes (each in a run of its own).  Run from the repository root on the GPU box;
+# writes under gpurun_out/.
+set -e
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+O=gpurun_out
+rm -rf $O/p5_stats $O/p5_fetch $O/p5_write
+timeout -k 10 300 python3 bench.py > $O/p5_bench.json 2> $O/p5_bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/p5_stats -o stats -- python3 bench.py --no-cpu-baseline > $O/p5_stats.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/p5_fetch -o fetch -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/p5_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/p5_write -o write -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/p5_write.log 2>&1
+echo done > $O/p5_done
