@@ -78,7 +78,7 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
             const double dO = 0.5 * (dOb[((size_t)i * k_ + l) * K + j] + dOb[((size_t)l * k_ + i) * K + j]);
             w.X[i * LD + l] = (dO - Sc[i * LD + l] * dw0) / w0 - sv.dmu[i] * mu[l] - mu[i] * sv.dmu[l];
         }
-        const double dnu = sens_direction<T>(w, sv);
+        const double dnu = sens_direction<T, T == 64, false>(w, sv, SensDir{0, nullptr, nullptr, nullptr, nullptr});
         for (int e = tid; e < k_ * k_; e += T) {
             const int i = e / k_, l = e - i * k_;
             double val;
@@ -263,6 +263,129 @@ __host__ __device__ inline size_t hess_lds_doubles(int q, int d) {
            hess_tab_doubles(q, d) + (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
 }
 
+// Dg pre-pass: Dg_a[l][m] = sum_k (p_a alpha_k - 2 W[a,k]) d2k(x_a,X_k)/dx_al dx_am, training points
+// staged in `tab` in chunks.  T threads; leaves a barrier behind.
+template <int T>
+__device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int npad, int q,
+                                                const lds_f64* xq, const lds_f64* pv, lds_f64* tab,
+                                                lds_f64* Dg, const double* __restrict__ Xtrain,
+                                                const double* __restrict__ alpha,
+                                                const double* __restrict__ Wrows) {
+    const int tid = threadIdx.x, d = kp.d, dl = (d + 1) | 1;
+    const size_t tabsz = hess_tab_doubles(q, d);
+    int ch = (int)((tabsz - 2 * q) / (2 * q + dl));
+    ch = (ch / 16) * 16;
+    if (ch > 64) ch = 64;
+    lds_f64* c1 = tab;                        // [q][ch+1]  coef * 2 var kappa'
+    lds_f64* c2 = c1 + q * (ch + 1);          // [q][ch+1]  coef * 4 var kappa''
+    lds_f64* Xc = c2 + q * (ch + 1);          // [ch][dl]
+    const int nsym = d * (d + 1) / 2;
+    const int nitems = q * nsym;             // per a: one item per (l <= m)
+    for (int e = tid; e < q * d * d; e += T) Dg[e] = 0.0;
+    for (int c0 = 0; c0 < n; c0 += ch) {
+        __syncthreads();
+        for (int e = tid; e < ch * d; e += T) {
+            const int k = e / d, l = e - k * d, kg = c0 + k;
+            Xc[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
+        }
+        __syncthreads();
+        for (int e = tid; e < q * ch; e += T) {
+            const int a = e / ch, k = e - a * ch, kg = c0 + k;
+            double v1 = 0.0, v2 = 0.0;
+            if (kg < n) {
+                double t = 0.0;
+                for (int l = 0; l < d; ++l) {
+                    const double df = xq[a * d + l] - Xc[k * dl + l];
+                    t += df * df * kp.inv_ls2[l];
+                }
+                double k0, k1, k2;
+                kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+                const double coef = pv[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg];
+                v1 = coef * 2.0 * kp.variance * k1;
+                v2 = coef * 4.0 * kp.variance * k2;
+            }
+            c1[a * (ch + 1) + k] = v1;
+            c2[a * (ch + 1) + k] = v2;
+        }
+        __syncthreads();
+        for (int e = tid; e < nitems; e += T) {
+            // entry (a, l, m2 >= l) and its mirror belong to this thread alone
+            const int a = e / nsym, it = e - a * nsym;
+            int l = 0, rem = it;
+            while (rem >= d - l) { rem -= d - l; ++l; }
+            const int m2 = l + rem;
+            double s = 0.0, s1 = 0.0;
+            const double xl = xq[a * d + l], xm = xq[a * d + m2];
+            for (int k = 0; k < ch; ++k) {
+                s += c2[a * (ch + 1) + k] * (xl - Xc[k * dl + l]) * (xm - Xc[k * dl + m2]);
+                s1 += c1[a * (ch + 1) + k];
+            }
+            s *= kp.inv_ls2[l] * kp.inv_ls2[m2];
+            if (m2 == l) s += s1 * kp.inv_ls2[l];       // 2 var kappa' delta_lm / ls_l^2
+            Dg[(a * d + l) * d + m2] += s;
+            if (m2 != l) Dg[(a * d + m2) * d + l] += s;
+        }
+    }
+    __syncthreads();
+}
+
+// self-covariance part of Dg: 2 sum_{c != a} M11_ac Hs_ac
+template <int T>
+__device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, const lds_f64* xq,
+                                                const lds_f64* M11, const lds_f64* k1s,
+                                                const lds_f64* k2s, lds_f64* Dg) {
+    const int d = kp.d;
+    for (int e = threadIdx.x; e < q * d * d; e += T) {
+        const int a = e / (d * d), rem = e - a * d * d, l = rem / d, m2 = rem - l * d;
+        double s = 0.0;
+        for (int c = 0; c < q; ++c) {
+            if (c == a) continue;
+            const double sdl = (xq[a * d + l] - xq[c * d + l]) * kp.inv_ls2[l];
+            const double sdm = (xq[a * d + m2] - xq[c * d + m2]) * kp.inv_ls2[m2];
+            s += M11[a * q + c] * (k2s[a * q + c] * sdl * sdm + (l == m2 ? k1s[a * q + c] * kp.inv_ls2[l] : 0.0));
+        }
+        Dg[e] += 2.0 * s;
+    }
+}
+
+// Row (a,l) of the Hessian from the direction's dN (q x LD), w1, w2, dN mu: the contraction with
+// every dOmega_(b,m) plus d2<Omega,M>/dx2 at fixed M.  `nth` threads numbered `tid` share the row.
+__device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams& kp, int q, int RP,
+                                              int a, int l, const lds_f64* dN, int LD,
+                                              const lds_f64* DS, const lds_f64* dmuT,
+                                              const lds_f64* w1, const lds_f64* w2,
+                                              const lds_f64* dNmu, const double* __restrict__ Gb,
+                                              const lds_f64* M11, const lds_f64* xq,
+                                              const lds_f64* k1s, const lds_f64* k2s,
+                                              const lds_f64* Dg, double* __restrict__ Hb,
+                                              const double* ttpre = nullptr) {
+    const int d = kp.d, dp = d + 1, qd = q * d, al = a * d + l;
+    int pass = 0;
+    for (int bm = tid; bm < qd; bm += nth, ++pass) {
+        const int bb = bm / d, m2 = bm - bb * d;
+        // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
+        double acc = 0.0;
+        const lds_f64* dsrow = DS + (size_t)bm * q;
+#pragma unroll 4
+        for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
+        double P = -acc + 2.0 * dmuT[bm] * (w1[bb] + w2[bb] - dNmu[bb]);
+        // d2<Omega,M>/dx2 at fixed M
+        // T_al . T_bm: the first two passes may have been fetched ahead by the caller
+        const double tt = (ttpre && pass < 2) ? (pass ? ttpre[1] : ttpre[0])
+                                              : gsym(Gb, RP, a * dp + 1 + l, bb * dp + 1 + m2);
+        double inner = 2.0 * M11[a * q + bb] * (dmuT[al] * dmuT[bm] - tt);
+        if (a != bb) {
+            const double sdl = (xq[a * d + l] - xq[bb * d + l]) * kp.inv_ls2[l];
+            const double sdm = (xq[a * d + m2] - xq[bb * d + m2]) * kp.inv_ls2[m2];
+            inner -= 2.0 * M11[a * q + bb] *
+                     (k2s[a * q + bb] * sdl * sdm + (l == m2 ? k1s[a * q + bb] * kp.inv_ls2[l] : 0.0));
+        } else {
+            inner += Dg[(a * d + l) * d + m2];
+        }
+        Hb[(size_t)al * qd + bm] = inner + P;
+    }
+}
+
 template <int T, int Q>
 __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double fmin, int n,
                                             int npad, int q, int RP,
@@ -298,65 +421,7 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
     if (tid < q) w.p[tid] = p_in[b * q + tid];
     __syncthreads();
 
-    // ---- Dg pre-pass: chunks of training points staged in `tab` ---------------------------------
-    {
-        const size_t tabsz = hess_tab_doubles(q, d);
-        int ch = (int)((tabsz - 2 * q) / (2 * q + dl));
-        ch = (ch / 16) * 16;
-        if (ch > 64) ch = 64;
-        lds_f64* c1 = tab;                        // [q][ch+1]  coef * 2 var kappa'
-        lds_f64* c2 = c1 + q * (ch + 1);          // [q][ch+1]  coef * 4 var kappa''
-        lds_f64* Xc = c2 + q * (ch + 1);          // [ch][dl]
-        const int nsym = d * (d + 1) / 2;
-        const int nitems = q * nsym;             // per a: one item per (l <= m)
-        for (int e = tid; e < q * d * d; e += T) Dg[e] = 0.0;
-        const double* Wrows = Wm + b * (size_t)q * npad;
-        for (int c0 = 0; c0 < n; c0 += ch) {
-            __syncthreads();
-            for (int e = tid; e < ch * d; e += T) {
-                const int k = e / d, l = e - k * d, kg = c0 + k;
-                Xc[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
-            }
-            __syncthreads();
-            for (int e = tid; e < q * ch; e += T) {
-                const int a = e / ch, k = e - a * ch, kg = c0 + k;
-                double v1 = 0.0, v2 = 0.0;
-                if (kg < n) {
-                    double t = 0.0;
-                    for (int l = 0; l < d; ++l) {
-                        const double df = xq[a * d + l] - Xc[k * dl + l];
-                        t += df * df * kp.inv_ls2[l];
-                    }
-                    double k0, k1, k2;
-                    kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
-                    const double coef = w.p[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg];
-                    v1 = coef * 2.0 * kp.variance * k1;
-                    v2 = coef * 4.0 * kp.variance * k2;
-                }
-                c1[a * (ch + 1) + k] = v1;
-                c2[a * (ch + 1) + k] = v2;
-            }
-            __syncthreads();
-            for (int e = tid; e < nitems; e += T) {
-                // entry (a, l, m2 >= l) and its mirror belong to this thread alone
-                const int a = e / nsym, it = e - a * nsym;
-                int l = 0, rem = it;
-                while (rem >= d - l) { rem -= d - l; ++l; }
-                const int m2 = l + rem;
-                double s = 0.0, s1 = 0.0;
-                const double xl = xq[a * d + l], xm = xq[a * d + m2];
-                for (int k = 0; k < ch; ++k) {
-                    s += c2[a * (ch + 1) + k] * (xl - Xc[k * dl + l]) * (xm - Xc[k * dl + m2]);
-                    s1 += c1[a * (ch + 1) + k];
-                }
-                s *= kp.inv_ls2[l] * kp.inv_ls2[m2];
-                if (m2 == l) s += s1 * kp.inv_ls2[l];       // 2 var kappa' delta_lm / ls_l^2
-                Dg[(a * d + l) * d + m2] += s;
-                if (m2 != l) Dg[(a * d + m2) * d + l] += s;
-            }
-        }
-        __syncthreads();
-    }
+    hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, tab, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
 
     // ---- tables, moments, state at the optimum --------------------------------------------------
     build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
@@ -373,18 +438,7 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
         w.S[a * LD + c] = kp.variance * k0 - gsym(Gb, RP, a * dp, c * dp) + (a == c ? noise : 0.0);
     }
     if (tid < q) w.dl[tid] = mu[tid] - fmin;
-    // self-covariance part of Dg: 2 sum_{c != a} M11_ac Hs_ac
-    for (int e = tid; e < q * d * d; e += T) {
-        const int a = e / (d * d), rem = e - a * d * d, l = rem / d, m2 = rem - l * d;
-        double s = 0.0;
-        for (int c = 0; c < q; ++c) {
-            if (c == a) continue;
-            const double sdl = (xq[a * d + l] - xq[c * d + l]) * kp.inv_ls2[l];
-            const double sdm = (xq[a * d + m2] - xq[c * d + m2]) * kp.inv_ls2[m2];
-            s += M11[a * q + c] * (k2s[a * q + c] * sdl * sdm + (l == m2 ? k1s[a * q + c] * kp.inv_ls2[l] : 0.0));
-        }
-        Dg[e] += 2.0 * s;
-    }
+    hess_dg_selfcov<T>(kp, q, xq, M11, k1s, k2s, Dg);
     __syncthreads();
     int sweeps = 0;
     int st = sdp_factor<T, Q>(w) ? 2 : 0;
@@ -409,7 +463,7 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
             else if (j == a) val = DS[al * q + i];
             w.X[i * LD + j] = val;
         }
-        const double dnu = sens_direction<T>(w, sv);
+        const double dnu = sens_direction<T, false, false>(w, sv, SensDir{0, nullptr, nullptr, nullptr, nullptr});
         (void)dnu;
         if (tid < q) {
             double acc = 0.0;
@@ -417,26 +471,181 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
             dNmu[tid] = acc;
         }
         __syncthreads();
-        for (int bm = tid; bm < qd; bm += T) {
-            const int bb = bm / d, m2 = bm - bb * d;
-            // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
-            double acc = 0.0;
-            const lds_f64* dsrow = DS + (size_t)bm * q;
-            for (int c = 0; c < q; ++c) acc += w.X[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
-            double P = -acc + 2.0 * dmuT[bm] * (sv.w1[bb] + sv.w2[bb] - dNmu[bb]);
-            // d2<Omega,M>/dx2 at fixed M
-            const double tt = gsym(Gb, RP, a * dp + 1 + l, bb * dp + 1 + m2);
-            double inner = 2.0 * M11[a * q + bb] * (dmuT[al] * dmuT[bm] - tt);
-            if (a != bb) {
-                const double sdl = (xq[a * d + l] - xq[bb * d + l]) * kp.inv_ls2[l];
-                const double sdm = (xq[a * d + m2] - xq[bb * d + m2]) * kp.inv_ls2[m2];
-                inner -= 2.0 * M11[a * q + bb] *
-                         (k2s[a * q + bb] * sdl * sdm + (l == m2 ? k1s[a * q + bb] * kp.inv_ls2[l] : 0.0));
-            } else {
-                inner += Dg[(a * d + l) * d + m2];
-            }
-            Hb[(size_t)al * qd + bm] = inner + P;
+        hess_contract(tid, T, kp, q, RP, a, l, w.X, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq, k1s, k2s, Dg, Hb);
+    }
+    if (tid == 0 && status) status[b] = 0;
+}
+
+// ---- register-path sizes (q <= 32): the same work in two kernels ---------------------------------
+// k_hess_prep (one wave per candidate) recomputes the solver state at the optimum and leaves what
+// the directions share in global memory; k_hess_dirs gives every candidate a workgroup of several
+// waves, each of which takes every NW-th direction through its own scratch matrices.  The q*d
+// directions of a candidate are independent, and one wave per candidate leaves most of the chip
+// idle for the batch sizes a BO loop produces.
+//
+// state per candidate: U, R, L (q x LD each), then rc, sq, rp, c, t1 (VL each)
+__host__ __device__ inline size_t hess_state_doubles(int q) {
+    return (size_t)3 * q * sdp_ld(q) + (size_t)5 * sdp_vlen(q);
+}
+
+template <int T, int Q>
+__global__ __launch_bounds__(T) void k_hess_prep(KernParams kp, double noise, double fmin, int q,
+                                                 int RP, const double* __restrict__ Xq,
+                                                 const double* __restrict__ G,
+                                                 const double* __restrict__ p_in,
+                                                 double* __restrict__ state,
+                                                 int* __restrict__ stflag) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    SdpWork w;
+    sdp_carve(w, sm, q, true);
+    const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d;
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, true);
+    SensVec sv;
+    sens_carve(sv, mu + VL, q);
+    lds_f64* xq = mu + VL + SENS_NVEC * VL;      // [q*d]
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const double* Gb = G + b * (size_t)RP * RP;
+    for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
+    if (tid < q) {
+        w.p[tid] = p_in[b * q + tid];
+        mu[tid] = gsym(Gb, RP, q * dp, tid * dp);
+        w.dl[tid] = mu[tid] - fmin;
+    }
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, c = e - a * q;
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - xq[c * d + l];
+            t += df * df * kp.inv_ls2[l];
         }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        w.S[a * LD + c] = kp.variance * k0 - gsym(Gb, RP, a * dp, c * dp) + (a == c ? noise : 0.0);
+    }
+    __syncthreads();
+    int sweeps = 0;
+    int st = sdp_factor<T, Q>(w) ? 2 : 0;
+    const double g = st ? -INFINITY : sdp_eval<T, Q>(w, w.p, sweeps, false);
+    if (!(g > -INFINITY)) st = 2;
+    if (!st && sens_prepare<T, Q>(w, mu, sv)) st = 2;
+    if (tid == 0) stflag[b] = st;
+    if (st) return;
+    double* sb = state + b * hess_state_doubles(q);
+    const int ML = q * LD;
+    for (int e = tid; e < ML; e += T) {
+        sb[e] = w.S[e];
+        sb[ML + e] = w.R[e];
+        sb[2 * ML + e] = w.H[e];
+    }
+    if (tid < q) {
+        double* vb = sb + 3 * ML;
+        vb[tid] = w.rc[tid];
+        vb[VL + tid] = w.sq[tid];
+        vb[2 * VL + tid] = w.rp[tid];
+        vb[3 * VL + tid] = sv.c[tid];
+        vb[4 * VL + tid] = sv.t1[tid];
+    }
+}
+
+#define HESS_WAVE_NVEC 9      // dmu dp rd t2 dc w1 w2 dNmu wv
+__host__ __device__ inline size_t hess_dirs_shared_doubles(int q, int d) {
+    // U R L phiS phiD | rc sq rp c t1 mu p | xq | tab | dmuT | k1s k2s M11 | Dg
+    return (size_t)5 * q * sdp_ld(q) + (size_t)7 * sdp_vlen(q) + (size_t)q * d + hess_tab_doubles(q, d) +
+           (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
+}
+__host__ __device__ inline size_t hess_dirs_wave_doubles(int q) {
+    return (size_t)2 * q * sdp_ld(q) + (size_t)HESS_WAVE_NVEC * sdp_vlen(q);
+}
+
+template <int T, int QE>
+__global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad, int q_arg, int RP,
+                                                 const double* __restrict__ Xtrain,
+                                                 const double* __restrict__ alpha,
+                                                 const double* __restrict__ Xq,
+                                                 const double* __restrict__ G,
+                                                 const double* __restrict__ Wm,
+                                                 const double* __restrict__ p_in,
+                                                 const double* __restrict__ M11_in,
+                                                 const double* __restrict__ state,
+                                                 const int* __restrict__ stflag,
+                                                 double* __restrict__ Hout, int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int NW = T / 64;
+    const int q = QE > 0 ? QE : q_arg;           // QE > 0: instance for exactly this q
+    const int VL = sdp_vlen(q), LD = sdp_ld(q), ML = q * LD, d = kp.d, qd = q * d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t b = blockIdx.x;
+    double* Hb = Hout + b * (size_t)qd * qd;
+    if (stflag[b]) {
+        for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
+        if (tid == 0 && status) status[b] = stflag[b];
+        return;
+    }
+    lds_f64* base = (lds_f64*)sm;
+    lds_f64* U = base;            lds_f64* R = U + ML;        lds_f64* L = R + ML;
+    lds_f64* phiS = L + ML;       lds_f64* phiD = phiS + ML;
+    lds_f64* rc = phiD + ML;      lds_f64* sq = rc + VL;      lds_f64* rp = sq + VL;
+    lds_f64* cv = rp + VL;        lds_f64* t1 = cv + VL;      lds_f64* mu = t1 + VL;
+    lds_f64* pv = mu + VL;
+    lds_f64* xq = pv + VL;                       // [q*d]
+    lds_f64* tab = xq + qd;                      // DS [q*d*q], first used as chunk staging
+    lds_f64* dmuT = tab + hess_tab_doubles(q, d);
+    lds_f64* k1s = dmuT + qd;
+    lds_f64* k2s = k1s + q * q;
+    lds_f64* M11 = k2s + q * q;
+    lds_f64* Dg = M11 + q * q;                   // [q][d][d]
+    lds_f64* wbase = Dg + q * d * d + (size_t)wave * hess_dirs_wave_doubles(q);
+    const double* Gb = G + b * (size_t)RP * RP;
+    for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
+    for (int e = tid; e < q * q; e += T) M11[e] = M11_in[b * q * q + e];
+    if (tid < q) pv[tid] = p_in[b * q + tid];
+    {
+        const double* sb = state + b * hess_state_doubles(q);
+        for (int e = tid; e < 3 * ML; e += T) U[e] = sb[e];               // U, R, L are adjacent
+        for (int e = tid; e < 5 * VL; e += T) rc[e] = sb[3 * ML + e];     // rc sq rp c t1 likewise
+    }
+    __syncthreads();
+    hess_dg_prepass<T>(kp, n, npad, q, xq, pv, tab, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
+    const lds_f64* DS = tab;
+    hess_dg_selfcov<T>(kp, q, xq, M11, k1s, k2s, Dg);
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, c = e - a * q;
+        const double sa = sq[a], sc = sq[c];
+        phiS[a * LD + c] = -0.5 * sdp_rcp(sa * sc * (sa + sc));
+        phiD[a * LD + c] = 0.5 * sdp_rcp(sa + sc);
+    }
+    __syncthreads();
+
+    // ---- directions: wave `wave` takes al = wave, wave + NW, ... ---------------------------------
+    SdpWork w;
+    w.q = q; w.LD = LD;
+    w.S = U; w.R = R; w.H = L; w.rc = rc; w.sq = sq; w.rp = rp;
+    w.X = w.Kt = wbase; w.V = wbase + ML;     // dN replaces Z: two scratch matrices per wave
+    lds_f64* wv0 = wbase + 2 * ML;
+    SensVec sv;
+    sv.dmu = wv0;            sv.dp = wv0 + VL;      sv.rd = wv0 + 2 * VL;  sv.t2 = wv0 + 3 * VL;
+    sv.dc = wv0 + 4 * VL;    sv.w1 = wv0 + 5 * VL;  sv.w2 = wv0 + 6 * VL;
+    lds_f64* dNmu = wv0 + 7 * VL;
+    lds_f64* wvec = wv0 + 8 * VL;
+    sv.c = cv; sv.t1 = t1;
+    for (int al = wave; al < qd; al += NW) {
+        const int a = al / d, l = al - a * d;
+        sens_sync<true>();
+        // the row's T_al . T_bm entries come from global memory: ask for them before the solve
+        double ttpre[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bm = min(lane + 64 * u, qd - 1), bb = bm / d, m2 = bm - bb * d;
+            ttpre[u] = gsym(Gb, RP, a * (d + 1) + 1 + l, bb * (d + 1) + 1 + m2);
+        }
+        if (lane < q) sv.dmu[lane] = (lane == a) ? dmuT[al] : 0.0;
+        sens_direction<64, true, true, QE>(w, sv, SensDir{a, DS + (size_t)al * q, wvec, phiS, phiD});
+        if (lane < q) dNmu[lane] = lds_dot(w.X + lane * LD, 1, mu, 1, q);
+        sens_sync<true>();
+        hess_contract(lane, 64, kp, q, RP, a, l, w.X, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq, k1s, k2s, Dg, Hb, ttpre);
     }
     if (tid == 0 && status) status[b] = 0;
 }
@@ -510,14 +719,18 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
     const int d = m->d, qd = q * d, npad = m->npad;
     const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
     const size_t lds = hess_lds_doubles(q, d) * sizeof(double);
-    const int chunk = 512;
+    // candidates per pass: bounded by the per-candidate workspace (E rows and Gram block, about
+    // 2 * RP * (npad + RP / 2) doubles), 2048 when that stays below ~4 GB
+    int chunk = 2048;
+    while (chunk > 64 && (double)chunk * RP * (2.0 * npad + RP) * sizeof(double) > 4e9) chunk /= 2;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = (B - b0 < chunk) ? B - b0 : chunk;
         const double* Xc = X + (size_t)b0 * qd;
         const size_t zrows = round_up_sz((size_t)Bc * q, 64);
         const size_t zbytes = zrows * npad * sizeof(double);
         const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
-        if ((rc = hess_front(m, Bc, q, Xc, RP, 2 * zbytes + Bc * sizeof(double) + Bc * sizeof(int), st))) return rc;
+        const size_t sbytes = (q <= 32) ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16 : 0;
+        if ((rc = hess_front(m, Bc, q, Xc, RP, 2 * zbytes + Bc * sizeof(double) + ((Bc + 1) & ~1) * sizeof(int) + sbytes, st))) return rc;
         double* Zb = m->hs + gbytes / sizeof(double);
         double* Wb = Zb + zrows * npad;
         double* valb = Wb + zrows * npad;
@@ -532,8 +745,26 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         double* Hc = H + (size_t)b0 * qd * qd;
         int* sc = status ? status + b0 : nullptr;
         if (q <= 32) {
-            if ((rc = set_lds_attr((k_hess<64, 32>), lds))) return rc;
-            hipLaunchKernelGGL((k_hess<64, 32>), dim3(Bc), dim3(64), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
+            // state + flags behind the buffers already carved from m->hs
+            double* state = reinterpret_cast<double*>(stb + ((Bc + 1) & ~1));
+            int* pflag = reinterpret_cast<int*>(state + (size_t)Bc * hess_state_doubles(q));
+            const size_t lds_prep = (sdp_work_doubles(q, true) + (size_t)(1 + SENS_NVEC) * sdp_vlen(q) + (size_t)qd) * sizeof(double);
+            if ((rc = set_lds_attr((k_hess_prep<64, 32>), lds_prep))) return rc;
+            hipLaunchKernelGGL((k_hess_prep<64, 32>), dim3(Bc), dim3(64), lds_prep, st, m->kp, m->noise, m->fmin, q, RP, Xc, m->hs, p_buf, state, pflag);
+            OEI_HIP_CHECK(hipGetLastError());
+            const size_t shared = hess_dirs_shared_doubles(q, d) * sizeof(double), per_wave = hess_dirs_wave_doubles(q) * sizeof(double);
+            const size_t budget = 160 * 1024;
+            if (shared + per_wave > budget) { oei_set_error("hessian_batched: q=%d d=%d needs %zu bytes of LDS (limit %zu)", q, d, shared + per_wave, budget); return OEI_ERR_ARG; }
+            int nw = (int)((budget - shared) / per_wave);
+            if (nw > qd) nw = qd;
+#define LAUNCH_DIRS(TT, QE) do { \
+                const size_t lds_d = shared + (size_t)((TT) / 64) * per_wave; \
+                if ((rc = set_lds_attr((k_hess_dirs<TT, QE>), lds_d))) return rc; \
+                hipLaunchKernelGGL((k_hess_dirs<TT, QE>), dim3(Bc), dim3(TT), lds_d, st, m->kp, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, state, pflag, Hc, sc); } while (0)
+            if (q == 20 && nw >= 8) LAUNCH_DIRS(512, 20);       // the batch size of the benchmark configurations
+            else if (nw >= 8) LAUNCH_DIRS(512, 0); else if (nw >= 4) LAUNCH_DIRS(256, 0);
+            else if (nw >= 2) LAUNCH_DIRS(128, 0); else LAUNCH_DIRS(64, 0);
+#undef LAUNCH_DIRS
         } else {
             if ((rc = set_lds_attr((k_hess<256, 0>), lds))) return rc;
             hipLaunchKernelGGL((k_hess<256, 0>), dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);

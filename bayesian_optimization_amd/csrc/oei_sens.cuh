@@ -89,46 +89,191 @@ __device__ __forceinline__ void lds_mm(int q, int LD, const lds_f64* A, const ld
     }
 }
 
-// One direction.  In: sv.dmu, dS (symmetric) in w.X.  Out: dN in w.X, sv.w1 = N dc, sv.w2 = dN c,
-// sv.dp, Z in w.Kt; returns dnu.  dM11 = -dN, dM[:q,q] = w1 + w2, dM[q][q] = -dnu.
-// Needs w.rc = 1 / diag(L) of the factor in w.H (sens_prepare).
-template <int T>
-__device__ double sens_direction(const SdpWork w, const SensVec sv) {
-    const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
+// sum_k a[k sa] b[k sb] over k < q, and sum_k r[k] s[k] (x[k sx] - 2 y[k]); the reads of ten (eight)
+// terms are issued together, so a 20-term sum pays the LDS latency twice instead of per term.
+__device__ __forceinline__ double lds_dot(const lds_f64* a, int sa, const lds_f64* b, int sb, int q) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = 0;
+    for (; k + 10 <= q; k += 10) {
+        double av[10], bv[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) { av[u] = a[(k + u) * sa]; bv[u] = b[(k + u) * sb]; }
+#pragma unroll
+        for (int u = 0; u < 10; u += 2) { acc0 = fma(av[u], bv[u], acc0); acc1 = fma(av[u + 1], bv[u + 1], acc1); }
+        SDP_READS_FIRST(20, 10);
+    }
+    for (; k < q; ++k) acc0 = fma(a[k * sa], b[k * sb], acc0);
+    return acc0 + acc1;
+}
+__device__ __forceinline__ double lds_dot_rs(const lds_f64* r, const lds_f64* s, const lds_f64* x, int sx,
+                                             const lds_f64* y, int q) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = 0;
+    for (; k + 8 <= q; k += 8) {
+        double rv[8], sv[8], xv[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { rv[u] = r[k + u]; sv[u] = s[k + u]; xv[u] = x[(k + u) * sx]; yv[u] = y[k + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            acc0 = fma(rv[u] * sv[u], fma(-2.0, yv[u], xv[u]), acc0);
+            acc1 = fma(rv[u + 1] * sv[u + 1], fma(-2.0, yv[u + 1], xv[u + 1]), acc1);
+        }
+        SDP_READS_FIRST(32, 24);
+    }
+    for (; k < q; ++k) acc0 = fma(r[k] * s[k], fma(-2.0, y[k], x[k * sx]), acc0);
+    return acc0 + acc1;
+}
+
+// Synchronisation between the phases of a direction: workgroup-wide, or -- when every wave works
+// on a direction of its own in private scratch (WAVE) -- nothing but a compiler fence: the LDS
+// serves the accesses of one wave in program order.
+template <bool WAVE>
+__device__ __forceinline__ void sens_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// The same product for one wave, register-blocked: a lane owns a BH x BW block of C, so a group
+// of BH + BW LDS reads feeds BH * BW multiply-adds (the element-per-lane form needs two reads per
+// multiply-add and is bound by LDS issue and latency).  Rows and columns past q are clamped for
+// the reads and not stored.
+template <int BH, int BW, bool TA, bool TB, bool SC>
+__device__ __forceinline__ void wave_mm_blk(int lane, int q, int LD, const lds_f64* A, const lds_f64* B,
+                                            lds_f64* C, const lds_f64* sc) {
+    const int nrb = (q + BH - 1) / BH, ncb = (q + BW - 1) / BW;
+    const int sa = TA ? LD : 1, sb = TB ? 1 : LD;
+    for (int blk = lane; blk < nrb * ncb; blk += 64) {
+        const int ib = blk / ncb, jb = blk - ib * ncb;
+        int ao[BH], bo[BW];
+#pragma unroll
+        for (int r = 0; r < BH; ++r) { const int i = min(ib * BH + r, q - 1); ao[r] = TA ? i : i * LD; }
+#pragma unroll
+        for (int c = 0; c < BW; ++c) { const int j = min(jb * BW + c, q - 1); bo[c] = TB ? j * LD : j; }
+        double acc[BH][BW];
+#pragma unroll
+        for (int r = 0; r < BH; ++r)
+#pragma unroll
+            for (int c = 0; c < BW; ++c) acc[r][c] = 0.0;
+        int k = 0;
+        for (; k + 4 <= q; k += 4) {
+            double av[4][BH], bv[4][BW], sv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < BH; ++r) av[u][r] = A[ao[r] + (k + u) * sa];
+#pragma unroll
+                for (int c = 0; c < BW; ++c) bv[u][c] = B[bo[c] + (k + u) * sb];
+                if (SC) sv4[u] = sc[k + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int r = 0; r < BH; ++r) {
+                    const double a = SC ? av[u][r] * sv4[u] : av[u][r];
+#pragma unroll
+                    for (int c = 0; c < BW; ++c) acc[r][c] = fma(a, bv[u][c], acc[r][c]);
+                }
+            }
+            SDP_READS_FIRST(4 * (BH + BW) + (SC ? 4 : 0), 4 * BH * BW + (SC ? 4 * BH : 0));
+        }
+        for (; k < q; ++k) {
+            double av[BH], bv[BW];
+#pragma unroll
+            for (int r = 0; r < BH; ++r) av[r] = A[ao[r] + k * sa] * (SC ? sc[k] : 1.0);
+#pragma unroll
+            for (int c = 0; c < BW; ++c) bv[c] = B[bo[c] + k * sb];
+#pragma unroll
+            for (int r = 0; r < BH; ++r)
+#pragma unroll
+                for (int c = 0; c < BW; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+        }
+#pragma unroll
+        for (int r = 0; r < BH; ++r)
+#pragma unroll
+            for (int c = 0; c < BW; ++c)
+                if (ib * BH + r < q && jb * BW + c < q) C[(ib * BH + r) * LD + jb * BW + c] = acc[r][c];
+    }
+}
+
+template <int T, bool WAVE, bool TA, bool TB, bool SC>
+__device__ __forceinline__ void sens_mm(int tid, int q, int LD, const lds_f64* A, const lds_f64* B,
+                                        lds_f64* C, const lds_f64* sc = nullptr) {
+    if constexpr (WAVE) {
+        if (q <= 16) wave_mm_blk<2, 2, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+        else if (q <= 20) wave_mm_blk<2, 4, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+        else wave_mm_blk<4, 4, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+    } else {
+        lds_mm<T, TA, TB, SC>(q, LD, A, B, C, sc);
+    }
+}
+
+// What a direction reads besides the solver state: the perturbation itself and, optionally,
+// the two coefficient matrices that do not depend on the direction.
+struct SensDir {
+    // RANK2 form: dS = e_a v'^T + v' e_a^T with v'_j = vrow[j] (j != a), v'_a = vrow[a] / 2
+    int a;
+    const lds_f64* vrow;
+    lds_f64* wv;                 // [q] scratch for U^T v'
+    // phiS[a][b] = -1 / (2 sq_a sq_b (sq_a + sq_b)),  phiD[a][b] = 1 / (2 (sq_a + sq_b)); or null
+    const lds_f64 *phiS, *phiD;
+};
+
+// One direction.  In: sv.dmu and dS -- a symmetric matrix in w.X, or in the RANK2 form of
+// SensDir.  Out: dN in w.X, sv.w1 = N dc, sv.w2 = dN c, sv.dp, Z in w.Kt; returns dnu.
+// dM11 = -dN, dM[:q,q] = w1 + w2, dM[q][q] = -dnu.
+// Needs w.rc = 1 / diag(L) of the factor in w.H (sens_prepare).  With WAVE the calling wave works
+// alone: w.X, w.V, w.Kt and the sv vectors other than c, t1 are its own, `T` is ignored.  In the
+// RANK2 form w.X is not an input and may be the same buffer as w.Kt (Z is then overwritten by dN).
+// QE > 0: q is known at compile time (q == QE), which turns the index arithmetic of the passes and
+// the strides of the products into constants.
+template <int T, bool WAVE, bool RANK2, int QE = 0>
+__device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec sv, const SensDir sd) {
+    constexpr int TT = WAVE ? 64 : T;
+    const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+    const int q = QE > 0 ? QE : w.q, LD = QE > 0 ? (QE | 1) : w.LD;
     const lds_f64* U = w.S;
     lds_f64* Ta = w.X;
     lds_f64* Tb = w.V;
     lds_f64* Tc = w.Kt;
-    __syncthreads();
-    lds_mm<T, false, false>(q, LD, Ta, U, Tb);            // Tb = dS U
-    __syncthreads();
-    lds_mm<T, true, false>(q, LD, U, Tb, Tc);             // Tc = U^T dS U
-    __syncthreads();
-    for (int e = tid; e < q * q; e += T) {                // ZS
-        const int a = e / q, b = e - a * q;
-        const double sa = w.sq[a], sb = w.sq[b];
-        Tc[a * LD + b] *= -0.5 * sdp_rcp(sa * sb * (sa + sb));
+    sens_sync<WAVE>();
+    if constexpr (RANK2) {
+        // U^T dS U = u wv^T + wv u^T with u = row a of U, wv = U^T v'
+        if (tid < q) {
+            const double acc = lds_dot(U + tid, LD, sd.vrow, 1, q);
+            sd.wv[tid] = acc - 0.5 * U[sd.a * LD + tid] * sd.vrow[sd.a];
+        }
+        sens_sync<WAVE>();
+        const lds_f64* ua = U + sd.a * LD;
+        for (int e = tid; e < q * q; e += TT) {            // ZS
+            const int a = e / q, b = e - a * q;
+            Tc[a * LD + b] = (ua[a] * sd.wv[b] + sd.wv[a] * ua[b]) * sd.phiS[a * LD + b];
+        }
+    } else {
+        sens_mm<T, WAVE, false, false, false>(tid, q, LD, Ta, U, Tb);            // Tb = dS U
+        sens_sync<WAVE>();
+        sens_mm<T, WAVE, true, false, false>(tid, q, LD, U, Tb, Tc);             // Tc = U^T dS U
+        sens_sync<WAVE>();
+        for (int e = tid; e < q * q; e += TT) {            // ZS
+            const int a = e / q, b = e - a * q;
+            const double sa = w.sq[a], sb = w.sq[b];
+            Tc[a * LD + b] *= sd.phiS ? sd.phiS[a * LD + b] : -0.5 * sdp_rcp(sa * sb * (sa + sb));
+        }
     }
-    __syncthreads();
+    sens_sync<WAVE>();
     // rhs = dmu - (dBS_ii - 2 (dBS p)_i)/4 with dBS = -4 Rs ZS Rs^T, Rs = R diag(sq):
     // M1 = ZS Rs^T (into Tb), t2 = ZS t1, rhs_i = dmu_i + sum_a Rs[i][a] (M1[a][i] - 2 t2[a])
-    lds_mm<T, false, true, true>(q, LD, Tc, w.R, Tb, w.sq);
-    if (tid < q) {
-        double acc = 0.0;
-        for (int b = 0; b < q; ++b) acc += Tc[tid * LD + b] * sv.t1[b];
-        sv.t2[tid] = acc;
-    }
-    __syncthreads();
+    sens_mm<T, WAVE, false, true, true>(tid, q, LD, Tc, w.R, Tb, w.sq);
+    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);
+    sens_sync<WAVE>();
     double rhs = 0.0;
-    if (tid < q) {
-        double acc = 0.0;
-#pragma unroll 4
-        for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * (Tb[a * LD + tid] - 2.0 * sv.t2[a]);
-        rhs = sv.dmu[tid] + acc;
-    }
+    if (tid < q) rhs = sv.dmu[tid] + lds_dot_rs(w.R + tid * LD, w.sq, Tb + tid, LD, sv.t2, q);
     // A x = rhs with A = L L^T = -hess g
-    if constexpr (T == 64) {
+    if constexpr (TT == 64) {
         // one wave: the running vector stays in a register, solved components are broadcast
         // through the scalar unit; L is read from LDS (reads do not depend on the chain)
         const int row = tid < q ? tid : 0;
@@ -166,50 +311,30 @@ __device__ double sens_direction(const SdpWork w, const SensVec sv) {
         }
         if (tid < q) sv.dp[tid] = -w.step[tid];
     }
-    __syncthreads();
-    if (tid < q) {
-        double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc += w.R[i * LD + tid] * sv.dp[i];
-        sv.rd[tid] = acc;
-    }
-    lds_mm<T, true, false, true>(q, LD, w.R, w.R, Tb, sv.dp);   // Tb = R^T diag(dp) R
-    __syncthreads();
-    for (int e = tid; e < q * q; e += T) {                // Z = ZS + Phi o (R^T dD R)/4
+    sens_sync<WAVE>();
+    if (tid < q) sv.rd[tid] = lds_dot(w.R + tid, LD, sv.dp, 1, q);
+    sens_mm<T, WAVE, true, false, true>(tid, q, LD, w.R, w.R, Tb, sv.dp);   // Tb = R^T diag(dp) R
+    sens_sync<WAVE>();
+    for (int e = tid; e < q * q; e += TT) {               // Z = ZS + Phi o (R^T dD R)/4
         const int a = e / q, b = e - a * q;
         const double acc = Tb[a * LD + b] - sv.rd[a] * w.rp[b] - w.rp[a] * sv.rd[b];
-        Tc[a * LD + b] += 0.5 * acc * sdp_rcp(w.sq[a] + w.sq[b]);
+        Tc[a * LD + b] += acc * (sd.phiD ? sd.phiD[a * LD + b] : 0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
-    __syncthreads();
-    lds_mm<T, false, true>(q, LD, Tc, U, Tb);             // Tb = Z U^T
+    sens_sync<WAVE>();
+    sens_mm<T, WAVE, false, true, false>(tid, q, LD, Tc, U, Tb);             // Tb = Z U^T
+    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);         // Z t1
+    sens_sync<WAVE>();
+    sens_mm<T, WAVE, false, false, false>(tid, q, LD, U, Tb, Ta);            // Ta = dN = U Z U^T
+    // dc = dmu + (dB p + B dp)/2 = dmu - 2 Rs (Z t1) + R (sq o rd)
+    if (tid < q) sv.dc[tid] = sv.dmu[tid] + lds_dot_rs(w.R + tid * LD, w.sq, sv.rd, 1, sv.t2, q);
+    sens_sync<WAVE>();
+    if (tid < q) sv.t2[tid] = lds_dot(U + tid, LD, sv.dc, 1, q) * sdp_rcp(w.sq[tid]);   // (U^T dc)/sq
+    sens_sync<WAVE>();
     if (tid < q) {
-        double acc = 0.0;
-        for (int b = 0; b < q; ++b) acc += Tc[tid * LD + b] * sv.t1[b];
-        sv.t2[tid] = acc;                                 // Z t1
+        sv.w1[tid] = 0.5 * lds_dot(U + tid * LD, 1, sv.t2, 1, q);      // N dc
+        sv.w2[tid] = lds_dot(Ta + tid * LD, 1, sv.c, 1, q);            // dN c
     }
-    __syncthreads();
-    lds_mm<T, false, false>(q, LD, U, Tb, Ta);            // Ta = dN = U Z U^T
-    if (tid < q) {        // dc = dmu + (dB p + B dp)/2 = dmu - 2 Rs (Z t1) + R (sq o rd)
-        double acc = 0.0;
-        for (int a = 0; a < q; ++a) acc += w.R[tid * LD + a] * w.sq[a] * (sv.rd[a] - 2.0 * sv.t2[a]);
-        sv.dc[tid] = sv.dmu[tid] + acc;
-    }
-    __syncthreads();
-    if (tid < q) {        // t2 = (U^T dc)/sq
-        double acc = 0.0;
-        for (int i = 0; i < q; ++i) acc += U[i * LD + tid] * sv.dc[i];
-        sv.t2[tid] = acc / w.sq[tid];
-    }
-    __syncthreads();
-    if (tid < q) {
-        double a1 = 0.0, a2 = 0.0;
-        for (int k = 0; k < q; ++k) {
-            a1 += U[tid * LD + k] * sv.t2[k];
-            a2 += Ta[tid * LD + k] * sv.c[k];
-        }
-        sv.w1[tid] = 0.5 * a1;                            // N dc
-        sv.w2[tid] = a2;                                  // dN c
-    }
-    __syncthreads();
+    sens_sync<WAVE>();
     double dnu = 0.0;
     for (int i = 0; i < q; ++i) dnu += sv.c[i] * (2.0 * sv.w1[i] + sv.w2[i]);
     return dnu;

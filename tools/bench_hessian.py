@@ -7,7 +7,7 @@ from bayesian_optimization_amd import DeviceGP
 
 model = hart6.make_model(310)
 gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
-for B in (1, 64, 512):
+for B in (1, 64, 256, 512, 2048):
     X = torch.as_tensor(np.random.RandomState(1).uniform(-.5, .5, (B, 20, 6)), device='cuda')
     gp.hessian(X); torch.cuda.synchronize()
     t0 = time.perf_counter()
