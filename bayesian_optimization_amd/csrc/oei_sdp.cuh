@@ -157,145 +157,263 @@ __device__ __forceinline__ void sdp_tri_index(int e, int& i, int& j) {
 }
 
 // ================================================================================================
-// LDS path (any workgroup size): two-sided cyclic Jacobi on w.X, eigenvectors in w.V
+// Wide path (several waves per candidate, any q <= 64): the same algorithm as the register path
+// with the columns of G in LDS.  State and conventions are those of the register path (Lc in w.S,
+// U in w.X, w.H = exchange buffer / Newton matrix), so three q x q matrices suffice here too.
 // ================================================================================================
-// Round-robin ordering: in round r, slot 0 pairs (qe-1, r) and slot k pairs ((r+k), (r-k)) mod
-// (qe-1); qe = q rounded up to even, pairs touching the padding index are idle.  For one round the
-// np x np grid of 2x2 blocks X[{i_k,j_k},{i_l,j_l}] <- J_k^T (.) J_l is updated independently.
+// value of the lane given by a DPP control word, for a double
+template <int CTRL>
+__device__ __forceinline__ double sdp_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the 8 lanes of an aligned group; every lane of the group gets the same bits (each
+// butterfly step adds the same two numbers in both partners).  All 64 lanes must be active.
+__device__ __forceinline__ double sdp_sum8(double v) {
+    v += sdp_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += sdp_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += sdp_dpp<0x141>(v);       // row_half_mirror
+    return v;
+}
+
+// In-place Cholesky of the lower triangle of A (q x q, leading dimension LD) by T threads.
+// Returns 1 at the first non-positive pivot (identical in every thread).
 template <int T>
-__device__ int sdp_jacobi(const SdpWork w) {
+__device__ int sdp_chol_lds(lds_f64* A, int q, int LD) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < q; ++k) {
+        const double akk = A[k * LD + k];
+        if (!(akk > 0.0)) return 1;
+        const double rinv = sdp_rsq(akk);
+        __syncthreads();
+        if (tid == 0) A[k * LD + k] = akk * rinv;
+        for (int i = k + 1 + tid; i < q; i += T) A[i * LD + k] *= rinv;
+        __syncthreads();
+        const int rem = q - k - 1;
+        for (int e = tid; e < rem * rem; e += T) {
+            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+            if (j <= i) A[i * LD + j] -= A[i * LD + k] * A[j * LD + k];
+        }
+        __syncthreads();
+    }
+    return 0;
+}
+
+// S = Lc Lc^T in place: Lc in the lower triangle of w.S, the strict upper triangle receives
+// Lc^-T (row i: entries r > i) and w.rc the reciprocal diagonal, so that the back substitution
+// U = Lc^-T (G V) of every evaluation becomes a product that all threads share.
+template <int T>
+__device__ int sdp_factor_wide(const SdpWork w) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
+    __syncthreads();
+    if (sdp_chol_lds<T>(w.S, q, LD)) return 1;
+    // thread j: column j of Lc^-1 by forward substitution, kept as row j of the upper triangle;
+    // a thread reads the factor and its own row only
+    if (tid < q) {
+        const int j = tid;
+        const double xj = sdp_rcp(w.S[j * LD + j]);
+        w.rc[j] = xj;
+        for (int i = j + 1; i < q; ++i) {
+            double acc = w.S[i * LD + j] * xj;
+            for (int k = j + 1; k < i; ++k) acc += w.S[i * LD + k] * w.S[j * LD + k];
+            w.S[j * LD + i] = -acc * sdp_rcp(w.S[i * LD + i]);
+        }
+    }
+    __syncthreads();
+    return 0;
+}
+
+// One-sided (Hestenes) Jacobi on the q columns of G, column j at Gc[j * LD + r].  Groups of 8
+// threads own one pair of columns per round (round-robin pairing: in round r, slot 0 pairs
+// (qe-1, r), slot k pairs (r+k, r-k) mod (qe-1); qe = q rounded up to even, a pair that touches
+// the padding index idles); thread s of a group holds the rows s, s+8, ... of both columns.
+template <int T>
+__device__ int sdp_jacobi_cols(lds_f64* Gc, int q, int LD, double tol2, double fin2) {
+    constexpr int NG = T / 8, MR = 8;           // rows per thread: q <= 64
+    const int tid = threadIdx.x, grp = tid >> 3, s = tid & 7;
     const int qe = q + (q & 1), np = qe >> 1, nm1 = qe - 1;
-    lds_f64* X = w.X;
-    lds_f64* V = w.V;
-    // Off-diagonal entries below the rounding level of the largest diagonal entry are noise that
-    // later rotations keep re-creating: rotating them away would never end.
-    double xmax = 0.0;
-    for (int i = 0; i < q; ++i) xmax = fmax(xmax, X[i * LD + i]);
-    const double floor2 = (4.0e-16 * xmax) * (4.0e-16 * xmax);
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
         int rotated = 0;
         for (int r = 0; r < nm1; ++r) {
-            int flag = 0;
-            if (tid < np) {
-                int a, b;
-                if (tid == 0) { a = nm1; b = r; }
-                else { a = r + tid; if (a >= nm1) a -= nm1; b = r - tid; if (b < 0) b += nm1; }
+            for (int k0 = 0; k0 < np; k0 += NG) {
+                const int k = k0 + grp;
+                int a = nm1, b = r;
+                if (k > 0) { a = r + k; if (a >= nm1) a -= nm1; b = r - k; if (b < 0) b += nm1; }
                 const int i = a < b ? a : b, j = a < b ? b : a;
-                double c = 1.0, s = 0.0, t = 0.0;
-                if (j < q) {
-                    const double xii = X[i * LD + i], xjj = X[j * LD + j], xij = X[i * LD + j];
-                    const double thr = SDP_JACOBI_TOL * SDP_JACOBI_TOL * fabs(xii * xjj);
-                    if (xij * xij > thr && xij * xij > floor2) {
-                        const double zeta = (xjj - xii) / (2.0 * xij);
-                        t = 1.0 / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        if (zeta < 0.0) t = -t;
-                        c = 1.0 / sqrt(1.0 + t * t);
-                        s = t * c;
-                        flag = 1;
-                    }
+                const bool active = (k < np) && (j < q);
+                lds_f64* ci = Gc + (active ? i : 0) * LD;
+                lds_f64* cj = Gc + (active ? j : 0) * LD;
+                double gi[MR], gj[MR];
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const int row = s + 8 * m;
+                    const bool in = row < q;
+                    const double x = ci[in ? row : 0], y = cj[in ? row : 0];
+                    gi[m] = in ? x : 0.0;
+                    gj[m] = in ? y : 0.0;
                 }
-                w.ri[tid] = i; w.rj[tid] = (j < q) ? j : -1;
-                w.rc[tid] = c; w.rs[tid] = s; w.rt[tid] = t;
-            }
-            const int any = __syncthreads_or(flag);
-            if (!any) continue;
-            rotated = 1;
-            const int nblk = np * np;
-            for (int e = tid; e < nblk + q * np; e += T) {
-                if (e < nblk) {
-                    const int k = e / np, l = e - k * np;
-                    const int ik = w.ri[k], jk = w.rj[k], il = w.ri[l], jl = w.rj[l];
-                    // a slot whose partner is the padding index (j < 0) is a lone row/column:
-                    // it is not rotated itself but still sees the other slots' rotations
-                    if (k == l) {
-                        if (jk < 0) continue;
-                        const double t = w.rt[k];
-                        const double xij = X[ik * LD + jk];
-                        X[ik * LD + ik] -= t * xij;
-                        X[jk * LD + jk] += t * xij;
-                        if (w.rs[k] != 0.0) { X[ik * LD + jk] = 0.0; X[jk * LD + ik] = 0.0; }
-                    } else {
-                        const bool hk = jk >= 0, hl = jl >= 0;
-                        const double ck = w.rc[k], sk = w.rs[k], cl = w.rc[l], sl = w.rs[l];
-                        const double a = X[ik * LD + il];
-                        const double b = hl ? X[ik * LD + jl] : 0.0;
-                        const double c = hk ? X[jk * LD + il] : 0.0;
-                        const double d = (hk && hl) ? X[jk * LD + jl] : 0.0;
-                        const double a1 = ck * a - sk * c, b1 = ck * b - sk * d;
-                        const double c1 = sk * a + ck * c, d1 = sk * b + ck * d;
-                        X[ik * LD + il] = cl * a1 - sl * b1;
-                        if (hl) X[ik * LD + jl] = sl * a1 + cl * b1;
-                        if (hk) X[jk * LD + il] = cl * c1 - sl * d1;
-                        if (hk && hl) X[jk * LD + jl] = sl * c1 + cl * d1;
+                double al = 0.0, be = 0.0, ga = 0.0;
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    al = fma(gi[m], gi[m], al);
+                    be = fma(gj[m], gj[m], be);
+                    ga = fma(gi[m], gj[m], ga);
+                }
+                al = sdp_sum8(al); be = sdp_sum8(be); ga = sdp_sum8(ga);
+                const double g2 = ga * ga, aa = al * be;
+                const bool rot = active && (g2 > tol2 * aa);
+                if (rot) {
+                    // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = beta - alpha
+                    const double d = be - al;
+                    const double x = fma(d, d, 4.0 * g2);
+                    const double h = x * sdp_rsq(x);
+                    double t = 2.0 * ga * sdp_rcp(fabs(d) + h);
+                    if (d < 0.0) t = -t;
+                    const double c = sdp_rsq(fma(t, t, 1.0)), sg = t * c;
+                    rotated |= (g2 > fin2 * aa) ? 1 : 0;
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        const int row = s + 8 * m;
+                        if (row < q) {
+                            ci[row] = c * gi[m] - sg * gj[m];
+                            cj[row] = sg * gi[m] + c * gj[m];
+                        }
                     }
-                } else {
-                    const int f = e - nblk;
-                    const int row = f / np, l = f - row * np;
-                    const int il = w.ri[l], jl = w.rj[l];
-                    if (jl < 0) continue;
-                    const double cl = w.rc[l], sl = w.rs[l];
-                    const double vi = V[row * LD + il], vj = V[row * LD + jl];
-                    V[row * LD + il] = cl * vi - sl * vj;
-                    V[row * LD + jl] = sl * vi + cl * vj;
                 }
             }
             __syncthreads();
         }
-        if (!rotated) break;
+        if (!__syncthreads_or(rotated)) { ++sweep; break; }
     }
     return sweep;
 }
 
-// Evaluate g, grad g and the eigen-state at the point pt (length q, in LDS).  Returns g, or -inf
-// when pt leaves the simplex or X loses positive definiteness numerically.  Needs w.S = S.
-// Leaves U in w.X, R in w.R, and the vectors sq, sv, rp, ip, s, grad.
+// Evaluate g, grad g and the eigen-state at pt.  Needs w.S, w.rc from sdp_factor_wide.  With
+// SDP_EVAL_WARM the previous state (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in
+// w.sv) seeds this one: G <- G V_prev.  Leaves U in w.X and the vectors sq, sv, rp, s, rs, ip,
+// wp, grad.  Returns g, or -inf when pt leaves the simplex or the matrix loses rank numerically.
 template <int T>
-__device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) {
+__device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
+    const int qb = (q + 1) >> 1;                  // 2 x 2 blocks per dimension
+    SDP_TIC(t_setup);
     double sum = 0.0, pmin = INFINITY;
-    for (int i = 0; i < q; ++i) { sum += pt[i]; pmin = fmin(pmin, pt[i]); }
+    for (int i = 0; i < q; ++i) { const double v = pt[i]; sum += v; pmin = fmin(pmin, v); }
     const double p0 = 1.0 - sum;
     if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
-    const double sp0 = sqrt(p0), gam = 1.0 / (1.0 + sp0), ip0 = 1.0 / p0;
-    __syncthreads();           // previous readers of s/tv/X/V are done
+    const double rsp0 = sdp_rsq(p0), sp0 = p0 * rsp0, ip0 = rsp0 * rsp0;
+    const double gam = sdp_rcp(1.0 + sp0), gamp = gam * rsp0;
+    lds_f64* Gc = w.H;                            // free during an evaluation
+    __syncthreads();                              // earlier readers of the vectors are done
     if (tid < q) {
-        w.s[tid] = sqrt(pt[tid]);
-        w.ip[tid] = 1.0 / pt[tid];
-        double acc = 0.0;
-        for (int j = 0; j < q; ++j) acc += w.S[tid * LD + j] * pt[j];
+        const double pj = pt[tid];
+        const double sj = pj * sdp_rsq(pj);
+        w.s[tid] = sj;
+        double acc = 0.0;                         // m = Lc^T p
+        for (int i = tid; i < q; ++i) acc += w.S[i * LD + tid] * pt[i];
         w.tv[tid] = acc;
+        w.ci[tid] = sj * w.rs[tid];               // s_new / s_prev (warm start only)
     }
     __syncthreads();
-    double tau = 0.0;
-    for (int i = 0; i < q; ++i) tau += pt[i] * w.tv[i];
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, j = e - i * q;
-        w.X[i * LD + j] = w.s[i] * w.s[j] * (w.S[i * LD + j] - gam * (w.tv[i] + w.tv[j]) + gam * gam * tau);
-        w.V[i * LD + j] = (i == j) ? 1.0 : 0.0;
+    if (!(mode & SDP_EVAL_WARM)) {
+        // column j of G = s_j (Lc^T e_j - gam m)
+        for (int e = tid; e < q * q; e += T) {
+            const int j = e / q, r = e - j * q;
+            const double l = w.S[j * LD + r];
+            Gc[j * LD + r] = w.s[j] * ((r <= j ? l : 0.0) - gam * w.tv[r]);
+        }
+        __syncthreads();
+    } else {
+        // Vp = diag(s_new / s_prev) (U_prev + wp sv^T) in place of U_prev, then
+        // G V_prev = Lc^T Vp - gam m (1^T Vp)
+        for (int e = tid; e < q * q; e += T) {
+            const int j = e / q, a = e - j * q;
+            w.X[j * LD + a] = w.ci[j] * fma(w.wp[j], w.sv[a], w.X[j * LD + a]);
+        }
+        __syncthreads();
+        if (tid < q) {
+            double acc = 0.0;
+            for (int j = 0; j < q; ++j) acc += w.X[j * LD + tid];
+            w.grad[tid] = acc;                    // scratch: the gradient is written at the end
+        }
+        __syncthreads();
+        for (int blk = tid; blk < qb * qb; blk += T) {
+            const int rb = blk / qb, ab = blk - rb * qb;
+            const int r0 = 2 * rb, a0 = 2 * ab;
+            const int r1 = min(r0 + 1, q - 1), a1 = min(a0 + 1, q - 1);
+            // j = r0: only row r0 of the block sees Lc[r0][r0]
+            const double l00 = w.S[r0 * LD + r0];
+            double c00 = l00 * w.X[r0 * LD + a0], c01 = l00 * w.X[r0 * LD + a1], c10 = 0.0, c11 = 0.0;
+#pragma unroll 4
+            for (int j = r0 + 1; j < q; ++j) {
+                const double l0 = w.S[j * LD + r0], l1 = w.S[j * LD + r1];
+                const double v0 = w.X[j * LD + a0], v1 = w.X[j * LD + a1];
+                c00 = fma(l0, v0, c00); c01 = fma(l0, v1, c01);
+                c10 = fma(l1, v0, c10); c11 = fma(l1, v1, c11);
+            }
+            const double m0 = gam * w.tv[r0], m1 = gam * w.tv[r1];
+            const double s0 = w.grad[a0], s1 = w.grad[a1];
+            Gc[a0 * LD + r0] = c00 - m0 * s0;
+            if (a0 + 1 < q) Gc[a1 * LD + r0] = c01 - m0 * s1;
+            if (r0 + 1 < q) {
+                Gc[a0 * LD + r1] = c10 - m1 * s0;
+                if (a0 + 1 < q) Gc[a1 * LD + r1] = c11 - m1 * s1;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    sweeps += sdp_jacobi<T>(w);
-    __syncthreads();
+    SDP_TOC(0, t_setup);
+    SDP_TIC(t_jac);
+    {
+        const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
+        const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
+        const double fin = loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
+        sweeps += sdp_jacobi_cols<T>(Gc, q, LD, tol * tol, fin * fin);
+    }
+    SDP_TOC(1, t_jac);
+    SDP_TIC(t_rest);
     int bad = 0;
     if (tid < q) {
-        const double lam = w.X[tid * LD + tid];
-        if (!(lam > 0.0)) bad = 1;
-        w.sq[tid] = sqrt(fmax(lam, 1e-300));
-        double acc = 0.0;                  // (s^T V)_a
-        for (int k = 0; k < q; ++k) acc += w.s[k] * w.V[k * LD + tid];
-        w.tv[tid] = acc;
+        double n2 = 0.0;
+        for (int r = 0; r < q; ++r) { const double x = Gc[tid * LD + r]; n2 = fma(x, x, n2); }
+        if (!(n2 > 0.0)) bad = 1;
+        w.sq[tid] = sqrt(fmax(n2, 1e-300));
+        const double pj = pt[tid], rs = sdp_rsq(pj);
+        w.rs[tid] = rs; w.ip[tid] = rs * rs; w.wp[tid] = gamp * pj;
+    }
+    // U = Lc^-T (G V): U[i][a] = rc_i G[i][a] + sum_{r > i} LinvT[i][r] G[r][a]
+    for (int blk = tid; blk < qb * qb; blk += T) {
+        const int ib = blk / qb, ab = blk - ib * qb;
+        const int i0 = 2 * ib, a0 = 2 * ab;
+        const int i1 = min(i0 + 1, q - 1), a1 = min(a0 + 1, q - 1);
+        const lds_f64* g0 = Gc + a0 * LD;
+        const lds_f64* g1 = Gc + a1 * LD;
+        double c00 = w.rc[i0] * g0[i0], c01 = w.rc[i0] * g1[i0];
+        double c10 = w.rc[i1] * g0[i1], c11 = w.rc[i1] * g1[i1];
+        if (i0 + 1 < q) {
+            const double l = w.S[i0 * LD + i1];
+            c00 = fma(l, g0[i1], c00); c01 = fma(l, g1[i1], c01);
+        }
+#pragma unroll 4
+        for (int r = i0 + 2; r < q; ++r) {
+            const double l0 = w.S[i0 * LD + r], l1 = w.S[i1 * LD + r];
+            const double v0 = g0[r], v1 = g1[r];
+            c00 = fma(l0, v0, c00); c01 = fma(l0, v1, c01);
+            c10 = fma(l1, v0, c10); c11 = fma(l1, v1, c11);
+        }
+        w.X[i0 * LD + a0] = c00;
+        if (a0 + 1 < q) w.X[i0 * LD + a1] = c01;
+        if (i0 + 1 < q) {
+            w.X[i1 * LD + a0] = c10;
+            if (a0 + 1 < q) w.X[i1 * LD + a1] = c11;
+        }
     }
     bad = __syncthreads_or(bad);
     if (bad) return -INFINITY;
-    for (int e = tid; e < q * q; e += T) {        // U = W^T V
-        const int i = e / q, a = e - i * q;
-        w.X[i * LD + a] = w.s[i] * w.V[i * LD + a] - gam * pt[i] * w.tv[a];
-    }
-    __syncthreads();
     if (tid < q) {
         double acc = 0.0;
         for (int i = 0; i < q; ++i) acc += w.X[i * LD + tid];
@@ -303,109 +421,22 @@ __device__ double sdp_eval_lds(const SdpWork w, const lds_f64* pt, int& sweeps) 
         w.rp[tid] = acc * ip0;
     }
     __syncthreads();
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, a = e - i * q;
-        w.R[i * LD + a] = sdp_R(w, i, a);
+    double t0 = 0.0, gval = 0.0;
+    for (int a = 0; a < q; ++a) {
+        const double sa = w.sq[a], ra = w.rp[a];
+        t0 = fma(sa * ra, ra, t0);
+        gval += sa - pt[a] * w.dl[a];
     }
-    __syncthreads();
-    if (tid < q) {
-        double db = 0.0, bp = 0.0;
+    if (tid < q) {     // grad_i = (sum_a sq_a U_ia^2) / (2 p_i^2) - (sum_a sq_a rp_a^2)/2 - delta_i
+        double d = 0.0;
 #pragma unroll 4
-        for (int a = 0; a < q; ++a) {
-            const double r = w.R[tid * LD + a], rs = r * w.sq[a];
-            db += r * rs;
-            bp += rs * w.rp[a];
-        }
-        w.grad[tid] = 0.5 * db - bp - w.dl[tid];      // diag(B)/4 - B p/2 - delta with B = 2 R sq R^T
+        for (int a = 0; a < q; ++a) { const double x = w.X[tid * LD + a]; d = fma(x * x, w.sq[a], d); }
+        const double ipi = w.ip[tid];
+        w.grad[tid] = 0.5 * (d * ipi * ipi - t0) - w.dl[tid];
     }
     __syncthreads();
-    double g = 0.0;
-    for (int a = 0; a < q; ++a) g += w.sq[a] - pt[a] * w.dl[a];
-    return g;
-}
-
-// Newton direction, LDS path: w.step = (-hess g)^-1 grad g at the state left by sdp_eval_lds.
-// A = -hess g = 1/2 (Q_ij - c_i - c_j + c_0) + (B/2)_ij with, for z^{ij}_a = w_ia w_ja,
-//   Q_ij = z^T K z,  c_i = (w_i o m)^T K (w_i o m),  c_0 = (m o m)^T K (m o m).
-// Overwrites w.X (w_i), w.Kt (K), w.H (factor), w.ci, w.step.  Returns 1 if A is not PD.
-template <int T>
-__device__ int sdp_newton_dir_lds(const SdpWork w) {
-    const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
-    lds_f64* Wv = w.X;
-    __syncthreads();
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, a = e - i * q;
-        const double m = w.sq[a] * w.rp[a];
-        Wv[i * LD + a] = w.R[i * LD + a] * w.sq[a] - m;
-        w.Kt[i * LD + a] = 1.0 / (w.sq[i] * w.sq[a] * (w.sq[i] + w.sq[a]));
-    }
-    __syncthreads();
-    const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
-    for (int e = tid; e < nitems; e += T) {
-        int i = 0, j = 0, kind = 2;
-        if (e < npair) { sdp_tri_index(e, i, j); kind = 0; }
-        else if (e < npair + q) { i = e - npair; kind = 1; }
-        double tot = 0.0, bh = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double ma = w.sq[a] * w.rp[a];
-            const double za = kind == 0 ? Wv[i * LD + a] * Wv[j * LD + a] : kind == 1 ? Wv[i * LD + a] * ma : ma * ma;
-            double inner = 0.5 * w.Kt[a * LD + a] * za;
-#pragma unroll 4
-            for (int b = 0; b < a; ++b) {
-                const double mb = w.sq[b] * w.rp[b];
-                const double zb = kind == 0 ? Wv[i * LD + b] * Wv[j * LD + b] : kind == 1 ? Wv[i * LD + b] * mb : mb * mb;
-                inner += w.Kt[a * LD + b] * zb;
-            }
-            tot += za * inner;
-            if (kind == 0) bh += w.R[i * LD + a] * w.R[j * LD + a] * w.sq[a];
-        }
-        if (kind == 0) w.H[i * LD + j] = tot + bh;
-        else if (kind == 1) w.ci[i] = tot;
-        else w.ci[q] = tot;
-    }
-    __syncthreads();
-    const double c0 = w.ci[q];
-    for (int e = tid; e < npair; e += T) {
-        int i, j;
-        sdp_tri_index(e, i, j);
-        w.H[i * LD + j] += c0 - w.ci[i] - w.ci[j];
-    }
-    __syncthreads();
-    int fail = 0;
-    for (int k = 0; k < q; ++k) {
-        const double akk = w.H[k * LD + k];
-        if (!(akk > 0.0)) { fail = 1; break; }     // identical in every thread
-        const double piv = sqrt(akk);
-        __syncthreads();
-        if (tid == 0) w.H[k * LD + k] = piv;
-        for (int i = k + 1 + tid; i < q; i += T) w.H[i * LD + k] /= piv;
-        __syncthreads();
-        const int rem = q - k - 1;
-        for (int e = tid; e < rem * rem; e += T) {
-            const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-            if (j <= i) w.H[i * LD + j] -= w.H[i * LD + k] * w.H[j * LD + k];
-        }
-        __syncthreads();
-    }
-    if (fail) return 1;
-    if (tid < q) w.step[tid] = w.grad[tid];
-    __syncthreads();
-    for (int k = 0; k < q; ++k) {          // forward: L y = grad
-        const double yk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = yk;
-        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
-        __syncthreads();
-    }
-    for (int k = q - 1; k >= 0; --k) {     // backward: L^T x = y
-        const double xk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = xk;
-        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
-        __syncthreads();
-    }
-    return 0;
+    SDP_TOC(2, t_rest);
+    return gval;
 }
 
 // ================================================================================================
@@ -790,9 +821,8 @@ __device__ __forceinline__ void sdp_item_store(const SdpWork w, int slot, double
     else if (slot != INT_MIN) w.ci[-1 - slot] = (slot == -1 - w.q) ? vq + vl : vl - vq;
 }
 
-template <int Q, bool EXACT, bool PAIR>
+template <int T, int Q, bool EXACT, bool PAIR>
 __device__ __forceinline__ void sdp_hess_items(const SdpWork w) {
-    constexpr int T = 64;
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
@@ -883,7 +913,7 @@ __device__ __forceinline__ int sdp_newton_dir_reg(const SdpWork w) {
         }
     }
     __syncthreads();
-    sdp_hess_items<Q, EXACT, (Q <= 20)>(w);
+    sdp_hess_items<T, Q, EXACT, (Q <= 20)>(w);
     __syncthreads();
     const double e0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
@@ -900,24 +930,74 @@ __device__ __forceinline__ int sdp_newton_dir_reg(const SdpWork w) {
     return f;
 }
 
-// ---- dispatch between the two paths: Q > 0 register path (T == 64), Q == 0 LDS path ------------
+// Newton direction, wide path: the quadratic forms of the register path spread over T threads (an
+// item keeps its z vector in registers, so the loops are unrolled for the largest q), then a
+// Cholesky factorisation and two triangular solves in LDS.  Same outputs as sdp_newton_dir_reg.
+template <int T>
+__device__ int sdp_newton_dir_wide(const SdpWork w) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    __syncthreads();
+    SDP_TIC(t_items);
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, b = e - a * q;
+        if (b < a) {
+            const double sa = w.sq[a], sb = w.sq[b];
+            w.H[b * LD + a] = sa * sb * sdp_rcp(sa + sb);
+        }
+    }
+    __syncthreads();
+    sdp_hess_items<T, OEI_MAX_Q, false, false>(w);
+    __syncthreads();
+    const double e0 = w.ci[q];
+    const int npair = q * (q + 1) / 2;
+    for (int e = tid; e < npair; e += T) {
+        int i, j;
+        sdp_tri_index(e, i, j);
+        w.H[i * LD + j] += e0 + w.ci[i] + w.ci[j];
+    }
+    __syncthreads();
+    SDP_TOC(4, t_items);
+    SDP_TIC(t_chol);
+    if (sdp_chol_lds<T>(w.H, q, LD)) return 1;
+    if (tid < q) w.step[tid] = w.grad[tid];
+    __syncthreads();
+    for (int k = 0; k < q; ++k) {          // forward: L y = grad
+        const double yk = w.step[k] / w.H[k * LD + k];
+        __syncthreads();
+        if (tid == k) w.step[k] = yk;
+        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
+        __syncthreads();
+    }
+    for (int k = q - 1; k >= 0; --k) {     // backward: L^T x = y
+        const double xk = w.step[k] / w.H[k * LD + k];
+        __syncthreads();
+        if (tid == k) w.step[k] = xk;
+        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
+        __syncthreads();
+    }
+    SDP_TOC(5, t_chol);
+    return 0;
+}
+
+// ---- dispatch between the two paths: Q > 0 register path (T == 64), Q == 0 wide path -----------
 // Inside the solver the register-path pieces are inlined (one call site each): a real call would
 // save and restore the callee-saved half of a 170-register frame through scratch memory every
 // time.  The kernels that use single pieces (sensitivities) call them out of line instead.
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ int sdp_factor_x(const SdpWork w) {
     if constexpr (Q > 0) return sdp_factor_reg<Q, EXACT>(w);
-    else return 0;                       // the LDS path keeps S itself
+    else return sdp_factor_wide<T>(w);
 }
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ double sdp_eval_x(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     if constexpr (Q > 0) return sdp_eval_reg<Q, EXACT>(w, pt, sweeps, mode);
-    else return sdp_eval_lds<T>(w, pt, sweeps);
+    else return sdp_eval_wide<T>(w, pt, sweeps, mode);
 }
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ int sdp_newton_dir_x(const SdpWork w) {
     if constexpr (Q > 0) return sdp_newton_dir_reg<Q, EXACT>(w);
-    else return sdp_newton_dir_lds<T>(w);
+    else return sdp_newton_dir_wide<T>(w);
 }
 template <int T, int Q, bool EXACT>
 __device__ __noinline__ int sdp_factor_call(const SdpWork w) { return sdp_factor_x<T, Q, EXACT>(w); }
@@ -931,18 +1011,18 @@ __device__ __noinline__ int sdp_newton_dir_call(const SdpWork w) { return sdp_ne
 template <int T, int Q>
 __device__ __forceinline__ int sdp_factor(const SdpWork w) {
     if constexpr (Q > 0) return (w.q == Q) ? sdp_factor_call<T, Q, true>(w) : sdp_factor_call<T, Q, false>(w);
-    else return 0;
+    else return sdp_factor_call<T, 0, false>(w);
 }
 template <int T, int Q>
 __device__ __forceinline__ double sdp_eval(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     if constexpr (Q > 0)
         return (w.q == Q) ? sdp_eval_call<T, Q, true>(w, pt, sweeps, mode) : sdp_eval_call<T, Q, false>(w, pt, sweeps, mode);
-    else return sdp_eval_lds<T>(w, pt, sweeps);
+    else return sdp_eval_call<T, 0, false>(w, pt, sweeps, mode);
 }
 template <int T, int Q>
 __device__ __forceinline__ int sdp_newton_dir(const SdpWork w) {
     if constexpr (Q > 0) return (w.q == Q) ? sdp_newton_dir_call<T, Q, true>(w) : sdp_newton_dir_call<T, Q, false>(w);
-    else return sdp_newton_dir_lds<T>(w);
+    else return sdp_newton_dir_call<T, 0, false>(w);
 }
 
 // ================================================================================================
@@ -1085,4 +1165,4 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
         else if ((q) <= 20) { CALL(64, 20); } else if ((q) <= 32) { CALL(64, 32); } \
         else { CALL(256, 0); } } while (0)
 // waves per SIMD the register budget is tuned for (launch bound of the solver kernels)
-#define SDP_MIN_WAVES(Q) ((Q) == 0 ? 1 : 2)
+#define SDP_MIN_WAVES(Q) 2

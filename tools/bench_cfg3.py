@@ -18,3 +18,11 @@ for B in (64, 512, 2048):
     dt = (time.perf_counter() - t0) / 3
     print('B=%5d  %.2f ms  %.0f evals/s  unsolved %d  stages %s' % (B, dt * 1e3, B / dt, int((st != 0).sum()),
           np.round(gp.stage_times_ms(), 2)))
+from bayesian_optimization_amd import sdp_batched
+omg = gp.omega(X[:256])
+t0 = time.perf_counter()
+_, _, _, st2, iters = sdp_batched(omg, gp.fmin, want_Y=False)
+torch.cuda.synchronize()
+print('sdp_batched 256: %.2f ms' % ((time.perf_counter() - t0) * 1e3))
+iters = iters.cpu().numpy()
+print('newton mean %.2f max %d  sweeps mean %.2f max %d' % ((iters & 0xffff).mean(), (iters & 0xffff).max(), (iters >> 16).mean(), (iters >> 16).max()))

@@ -5,9 +5,9 @@ from bayesian_optimization_amd import DeviceGP, sdp_batched
 from oracle import hart6, gp as ogp
 q = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-model = hart6.make_model(310)
-gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
-X = np.random.RandomState(1).uniform(-.5, .5, (B, q, 6))
+model = hart6.make_model(310) if q <= 20 else hart6.make_model(310, d=10, lengthscale=0.8)
+gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, model.kernel.lengthscales, 1e-6, floor_mode=1)
+X = np.random.RandomState(1).uniform(-.5, .5, (B, q, model.X.shape[1]))
 om = gp.omega(X)
 value, M, _, st, it = sdp_batched(om, gp.fmin, want_Y=False)
 cyc = M.reshape(B, -1)[:, :8].cpu().numpy()
