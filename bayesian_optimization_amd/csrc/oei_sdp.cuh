@@ -930,13 +930,185 @@ __device__ __forceinline__ int sdp_newton_dir_reg(const SdpWork w) {
     return f;
 }
 
-// Newton direction, wide path: the quadratic forms of the register path spread over T threads (an
-// item keeps its z vector in registers, so the loops are unrolled for the largest q), then a
-// Cholesky factorisation and two triangular solves in LDS.  Same outputs as sdp_newton_dir_reg.
+// ---- Newton direction, wide path ------------------------------------------------------------------
+// Order of the LDS accesses of one wave without a workgroup barrier (the LDS serves one wave's
+// accesses in program order; this only stops the compiler from moving them).
+__device__ __forceinline__ void sdp_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// z vector of a work item as in sdp_item_z, zero beyond q, with the reads of eight entries issued
+// together.  Reads run up to 7 entries past q inside the LDS allocation; those products are
+// replaced by zeros.
+template <int QM>
+__device__ __forceinline__ void sdp_item_z_wide(const SdpWork w, int LD, int e, int npair, double (&z)[QM],
+                                                double& lf, double& scale, int& slot) {
+    const int q = __builtin_amdgcn_readfirstlane(w.q);
+    const bool k0 = e < npair, k1 = !k0 && e < npair + q, k2 = e == npair + q;
+    int i, j;
+    sdp_tri_index(k0 ? e : 0, i, j);
+    const int ia = k1 ? e - npair : i;
+    const lds_f64* A = (k0 || k1) ? w.X + ia * LD : w.rp;
+    const lds_f64* B = k0 ? w.X + j * LD : w.rp;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int a0 = 0; a0 < QM; a0 += 8) {
+        if (a0 < q) {
+            double av[8], bv[8], sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = A[a0 + u]; bv[u] = B[a0 + u]; sv[u] = w.sq[a0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double zz = (a0 + u < q) ? av[u] * bv[u] : 0.0;
+                z[a0 + u] = zz;
+                if (u & 1) acc1 = fma(zz, (a0 + u < q) ? sv[u] : 0.0, acc1);
+                else acc0 = fma(zz, (a0 + u < q) ? sv[u] : 0.0, acc0);
+            }
+            SDP_READS_FIRST(24, 24);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) z[a0 + u] = 0.0;
+        }
+    }
+    const double ipi = w.ip[ia], ipj = w.ip[j];
+    scale = ((k0 || k1) ? ipi : 1.0) * (k0 ? ipj : 1.0);
+    lf = acc0 + acc1;
+    slot = k0 ? i * LD + j : k1 ? -1 - ia : k2 ? -1 - q : INT_MIN;
+}
+
+// z^T K' z with K'(b, a), a > b, at Kt[b * LD + a]: row b is walked in groups of 16 contiguous
+// entries whose reads are issued together.  A group may run past column q - 1 into the following
+// row (or the matrix behind w.H): whatever finite numbers sit there meet the zeros of z.
+template <int QM>
+__device__ __forceinline__ double sdp_quadform_wide(const double (&z)[QM], const SdpWork w, int LD, int q) {
+    double tot = 0.0;
+    const lds_f64* Kt = w.H;
+#pragma unroll
+    for (int b = 0; b < QM; ++b) {
+        if (b < q) {
+            const lds_f64* row = Kt + b * LD;
+            double i0 = 0.25 * w.sq[b] * z[b], i1 = 0.0;
+#pragma unroll
+            for (int a0 = b + 1; a0 < QM; a0 += 16) {
+                if (a0 < q) {
+                    constexpr int dummy = 0;
+                    double kv[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) kv[u] = (a0 + u < QM) ? row[a0 + u] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const double zz = z[(a0 + u < QM) ? a0 + u : dummy];
+                        if (a0 + u < QM) { if (u & 1) i1 = fma(kv[u], zz, i1); else i0 = fma(kv[u], zz, i0); }
+                    }
+                    SDP_READS_FIRST(16, 16);
+                }
+            }
+            tot = fma(z[b], i0 + i1, tot);
+        }
+    }
+    return 2.0 * tot;
+}
+
+// Cholesky of A (lower triangle of w.H) and the solve A step = grad by the first wave alone:
+// lane i keeps row i in registers, pivots and multipliers travel through the scalar unit.  Rows
+// and columns past q hold zeros, so only the outer loops test q.  L goes back to w.H (lower).
+// Called by every thread; contains no workgroup barrier; the caller synchronises afterwards.
+template <int QM>
+__device__ __forceinline__ int sdp_chol_solve_wave0(const SdpWork w) {
+    const int lane = threadIdx.x;
+    const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
+    int fail = 0;
+    if (lane < 64) {
+        const bool act = lane < q;
+        const int row = act ? lane : 0;
+        double a[QM];
+#pragma unroll
+        for (int k0 = 0; k0 < QM; k0 += 16) {
+            if (k0 < q) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int k = k0 + u;
+                    const double h = w.H[row * LD + k];
+                    a[k] = (act && k <= lane && k < q) ? h : 0.0;
+                }
+                SDP_READS_FIRST(16, 32);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a[k0 + u] = 0.0;
+            }
+        }
+        double dinv = 0.0;
+#pragma unroll
+        for (int k = 0; k < QM; ++k) {
+            if (k < q) {
+                const double akk = sdp_lane_bcast(a[k], k);
+                if (!(akk > 0.0)) fail = 1;              // identical in every lane
+                const double rinv = sdp_rsq(akk);
+                const double lik = (lane >= k) ? a[k] * rinv : 0.0;
+                a[k] = lik;
+                if (lane == k) dinv = rinv;
+#pragma unroll
+                for (int j0 = k + 1; j0 < QM; j0 += 8) {
+                    if (j0 < q) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (j0 + u < QM) { const double ljk = sdp_lane_bcast(lik, j0 + u); a[j0 + u] -= lik * ljk; }
+                        }
+                    }
+                }
+            }
+        }
+        if (!fail) {
+            if (act) {
+#pragma unroll
+                for (int k = 0; k < QM; ++k) if (k < q && k <= lane) w.H[row * LD + k] = a[k];
+            }
+            double bv = act ? w.grad[row] : 0.0;
+#pragma unroll
+            for (int k = 0; k < QM; ++k) {                   // forward: L y = grad, column oriented
+                if (k < q) {
+                    const double yk = sdp_lane_bcast(bv * dinv, k);
+                    bv = (lane == k) ? yk : bv - a[k] * yk;  // a[k] = 0 in lanes < k
+                }
+            }
+            sdp_wave_sync();
+#pragma unroll
+            for (int k0 = 0; k0 < QM; k0 += 16) {            // column `lane` of L = row of L^T
+                if (k0 < q) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int k = k0 + u;
+                        const double h = w.H[(k < q ? k : 0) * LD + row];
+                        a[k] = (act && k >= lane && k < q) ? h : 0.0;
+                    }
+                    SDP_READS_FIRST(16, 32);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a[k0 + u] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = QM - 1; k >= 0; --k) {              // backward: L^T x = y
+                if (k < q) {
+                    const double xk = sdp_lane_bcast(bv * dinv, k);
+                    bv = (lane == k) ? xk : bv - a[k] * xk;  // a[k] = 0 in lanes > k
+                }
+            }
+            if (act) w.step[lane] = bv;
+        }
+    }
+    return fail;
+}
+
+// The quadratic forms of the register path spread over T threads (an item keeps its z vector in
+// registers, so the loops are unrolled for the largest q), then the factorisation and the solves
+// in the first wave.  Same outputs as sdp_newton_dir_reg.
 template <int T>
 __device__ int sdp_newton_dir_wide(const SdpWork w) {
     const int tid = threadIdx.x;
-    const int q = w.q, LD = w.LD;
+    const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
     __syncthreads();
     SDP_TIC(t_items);
     for (int e = tid; e < q * q; e += T) {
@@ -947,7 +1119,16 @@ __device__ int sdp_newton_dir_wide(const SdpWork w) {
         }
     }
     __syncthreads();
-    sdp_hess_items<T, OEI_MAX_Q, false, false>(w);
+    {
+        const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
+        for (int e0 = tid; e0 < nitems; e0 += T) {
+            double z0[OEI_MAX_Q];
+            int s0;
+            double l0, c0;
+            sdp_item_z_wide<OEI_MAX_Q>(w, LD, e0, npair, z0, l0, c0, s0);
+            sdp_item_store(w, s0, sdp_quadform_wide<OEI_MAX_Q>(z0, w, LD, q), l0, c0);
+        }
+    }
     __syncthreads();
     const double e0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
@@ -959,25 +1140,9 @@ __device__ int sdp_newton_dir_wide(const SdpWork w) {
     __syncthreads();
     SDP_TOC(4, t_items);
     SDP_TIC(t_chol);
-    if (sdp_chol_lds<T>(w.H, q, LD)) return 1;
-    if (tid < q) w.step[tid] = w.grad[tid];
-    __syncthreads();
-    for (int k = 0; k < q; ++k) {          // forward: L y = grad
-        const double yk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = yk;
-        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
-        __syncthreads();
-    }
-    for (int k = q - 1; k >= 0; --k) {     // backward: L^T x = y
-        const double xk = w.step[k] / w.H[k * LD + k];
-        __syncthreads();
-        if (tid == k) w.step[k] = xk;
-        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
-        __syncthreads();
-    }
+    const int fail = __syncthreads_or(sdp_chol_solve_wave0<OEI_MAX_Q>(w));
     SDP_TOC(5, t_chol);
-    return 0;
+    return fail;
 }
 
 // ---- dispatch between the two paths: Q > 0 register path (T == 64), Q == 0 wide path -----------

@@ -4,7 +4,7 @@
 set -e
 D=$(mktemp -d)
 for f in oei_model oei_gemm oei_sdp oei_acq oei_hess oei_fit; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DOEI_SDP_TIMING -c bayesian_optimization_amd/csrc/$f.hip -o $D/$f.o 2>/dev/null &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 --offload-arch=gfx950 -DOEI_SDP_TIMING -c bayesian_optimization_amd/csrc/$f.hip -o $D/$f.o 2>/dev/null &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboei_timing.so $D/*.o
