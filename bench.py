@@ -175,6 +175,18 @@ def main():
                     'stage_ms': dict(zip(names, [float(x) for x in stage])),
                     'dominant_stage': names[dom],
                     'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
+        # Hessian throughput of the same model and candidates (second half of the metric), outside
+        # the timed region: a few calls on a slice of this rank's candidates
+        hb = min(B, 2048)
+        gp.hessian(X_local[:hb])
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(3):
+            _, hst = gp.hessian(X_local[:hb])
+        torch.cuda.synchronize()
+        th = (time.perf_counter() - th) / 3
+        hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
+                   'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item())}
         cpu = None
         if not args.no_cpu_baseline:
             v, done, secs = cpu_baseline(model, X_local[:24].cpu().numpy())
@@ -194,7 +206,7 @@ def main():
                                       % (world, 8 * (2 + q * d))},
             'unconverged': n_bad,
             'best': {'value': float(best[0].item()), 'index': int(best[1].item())},
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'hessian': hessian, 'roofline': roofline, 'cpu_baseline': cpu,
         }
         print(json.dumps(result))
     if world > 1:

@@ -6,9 +6,9 @@ set -e
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out
-rm -rf $O/p5_stats $O/p5_fetch $O/p5_write
-timeout -k 10 300 python3 bench.py > $O/p5_bench.json 2> $O/p5_bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/p5_stats -o stats -- python3 bench.py --no-cpu-baseline > $O/p5_stats.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/p5_fetch -o fetch -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/p5_fetch.log 2>&1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/p5_write -o write -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/p5_write.log 2>&1
-echo done > $O/p5_done
+rm -rf $O/p6_stats $O/p6_fetch $O/p6_write
+timeout -k 10 300 python3 bench.py > $O/p6_bench.json 2> $O/p6_bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/p6_stats -o stats -- python3 bench.py --no-cpu-baseline > $O/p6_stats.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/p6_fetch -o fetch -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/p6_fetch.log 2>&1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/p6_write -o write -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 1 > $O/p6_write.log 2>&1
+echo done > $O/p6_done
