@@ -103,7 +103,7 @@ __device__ __forceinline__ void posterior_moments(const SdpWork w, const KernPar
 
 // LDS of the per-candidate kernels: the solver region (with the A-row staging buffers Ac [q][CH+1]
 // and vc [CH] overlaid on everything behind w.H, which is idle while rows are staged), then
-// mu [q+2] and xq [q*d].  `full`: six-matrix solver layout (LDS path), else three.
+// mu [q+2] and xq [q*d].  `full`: six-matrix layout (sensitivity kernels), else three.
 __host__ __device__ inline size_t acq_stage_doubles(int q) { return (size_t)q * (CH + 1) + CH; }
 __host__ __device__ inline size_t acq_lds_doubles(int q, int d, bool full) {
     return sdp_region_doubles(q, acq_stage_doubles(q), full) + (size_t)(q + 2) + (size_t)q * d;

@@ -206,6 +206,99 @@ __device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
     }
 }
 
+// The same tile with 128 rows: wave w owns rows [32w, 32w+32) x 64 columns as eight accumulators,
+// so every B fragment read from LDS feeds two MFMAs and a workgroup does twice the work per
+// prologue, barrier and epilogue.
+#define GM_BM2 128
+__device__ __forceinline__ void gemm_tile_nt_tall(const double* __restrict__ Ag0,
+                                                  const double* __restrict__ Bg0,
+                                                  double* __restrict__ Cg, int ld, int ldc, int kbeg,
+                                                  int kend, double* As, double* Bs) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int srow = tid >> 2;
+    const int scol = (tid & 3) * 4;
+    const double* Ag = Ag0 + (size_t)srow * ld + scol;
+    const double* Ah = Ag + (size_t)64 * ld;
+    const double* Bg = Bg0 + (size_t)srow * ld + scol;
+
+    double4_t acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+    double2 a0, a1, c0, c1, b0, b1;
+    a0 = *reinterpret_cast<const double2*>(Ag + kbeg);
+    a1 = *reinterpret_cast<const double2*>(Ag + kbeg + 2);
+    c0 = *reinterpret_cast<const double2*>(Ah + kbeg);
+    c1 = *reinterpret_cast<const double2*>(Ah + kbeg + 2);
+    b0 = *reinterpret_cast<const double2*>(Bg + kbeg);
+    b1 = *reinterpret_cast<const double2*>(Bg + kbeg + 2);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
+        double* as = As + buf * (GM_BM2 * GM_LDS);
+        double* bs = Bs + buf * (GM_BN * GM_LDS);
+        as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
+        as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
+        as[(srow + 64) * GM_LDS + scol + 0] = c0.x; as[(srow + 64) * GM_LDS + scol + 1] = c0.y;
+        as[(srow + 64) * GM_LDS + scol + 2] = c1.x; as[(srow + 64) * GM_LDS + scol + 3] = c1.y;
+        bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
+        bs[srow * GM_LDS + scol + 2] = b1.x; bs[srow * GM_LDS + scol + 3] = b1.y;
+        __syncthreads();
+        if (k0 + GM_BK < kend) {   // prefetch the next K step while this one is multiplied
+            a0 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK);
+            a1 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK + 2);
+            c0 = *reinterpret_cast<const double2*>(Ah + k0 + GM_BK);
+            c1 = *reinterpret_cast<const double2*>(Ah + k0 + GM_BK + 2);
+            b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
+            b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
+        }
+        const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < GM_BK / 4; ++ks) {
+            const double av0 = as[(wave * 32 + li) * GM_LDS + ks * 4 + lk];
+            const double av1 = as[(wave * 32 + 16 + li) * GM_LDS + ks * 4 + lk];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + lk];
+                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv, acc[1][t], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const size_t row = wave * 32 + h * 16 + rq + 4 * g;
+                Cg[row * ldc + t * 16 + col] = acc[h][t][g];
+            }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_nt_tall(const double* __restrict__ A,
+                                                      const double* __restrict__ Bm,
+                                                      double* __restrict__ C, int npad, int lower,
+                                                      unsigned nrb) {
+    __shared__ __attribute__((aligned(16))) double As[2 * GM_BM2 * GM_LDS];
+    __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
+    // same workgroup order as k_gemm_nt: the column tiles of one row panel share an XCD (one L2)
+    const int nt = npad / GM_BN;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const size_t rb = (size_t)(slot / nt) * 8 + xcd;
+    if (rb >= nrb) return;
+    const int j0 = (int)(slot % nt) * GM_BN;
+    const size_t r0 = rb * GM_BM2;
+    const int kbeg = lower ? 0 : j0;
+    const int kend = lower ? (j0 + GM_BN) : npad;
+    gemm_tile_nt_tall(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+}
+
 __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
                                                  const double* __restrict__ Bm,
                                                  double* __restrict__ C, int npad, int lower,
@@ -232,9 +325,16 @@ int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows
         oei_set_error("gemm_nt: rows_pad=%zu / npad=%d not tile multiples", rows_pad, npad);
         return OEI_ERR_ARG;
     }
-    const unsigned nrb = (unsigned)(rows_pad / GM_BM), nt = (unsigned)(npad / GM_BN);
-    dim3 grid(((nrb + 7) / 8) * 8 * nt);
-    hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, A, Bm, C, npad, lower, nrb);
+    const unsigned nt = (unsigned)(npad / GM_BN);
+    if (rows_pad % GM_BM2 == 0) {
+        const unsigned nrb = (unsigned)(rows_pad / GM_BM2);
+        dim3 grid(((nrb + 7) / 8) * 8 * nt);
+        hipLaunchKernelGGL(k_gemm_nt_tall, grid, dim3(256), 0, st, A, Bm, C, npad, lower, nrb);
+    } else {
+        const unsigned nrb = (unsigned)(rows_pad / GM_BM);
+        dim3 grid(((nrb + 7) / 8) * 8 * nt);
+        hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, st, A, Bm, C, npad, lower, nrb);
+    }
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

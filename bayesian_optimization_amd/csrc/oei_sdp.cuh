@@ -33,8 +33,9 @@
 //     needs is expressed through U, so three q x q matrices of LDS suffice (Lc, U and one that
 //     holds the Hessian in its lower and the Loewner kernel in its upper triangle): the small
 //     footprint is what lets ten and more candidates share a compute unit.
-//   * LDS path (larger q, 256 threads, Q = 0): two-sided Jacobi on X in LDS, rotations applied as
-//     independent 2x2 blocks; six matrices.
+//   * wide path (larger q, 256 threads, Q = 0): the same iteration with the columns of G in LDS;
+//     groups of 8 threads own a pair of columns per round and reduce with DPP shuffles.  Same
+//     state and the same three matrices.
 // All matrices are q x q with an odd leading dimension LD so that row and column walks are free
 // of LDS bank conflicts.  Every thread of the workgroup executes every call (barriers inside).
 #pragma once
@@ -82,9 +83,9 @@ typedef __attribute__((address_space(3))) int lds_i32;
 struct SdpWork {
     int q, LD;
     lds_f64 *H, *S, *X;                   // q x LD matrices, both layouts
-    lds_f64 *V, *R, *Kt;                  // full layout only (LDS path, sensitivity kernels)
+    lds_f64 *V, *R, *Kt;                  // full layout only (sensitivity kernels)
     lds_f64 *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci, *ip, *wp;   // vectors
-    lds_f64 *rc, *rs, *rt;                // 1/diag(Lc) | 1/s or rotation parameters (LDS path)
+    lds_f64 *rc, *rs, *rt;                // 1/diag(Lc) | 1/s
     lds_i32 *ri, *rj;
     lds_f64 *scal;                        // [8] scalars
 };
@@ -1324,7 +1325,7 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
     return nu;
 }
 
-// Host-side choice of the kernel instance for a given q: CALL(T, Q) with Q = 0 for the LDS path.
+// Host-side choice of the kernel instance for a given q: CALL(T, Q) with Q = 0 for the wide path.
 #define SDP_DISPATCH_Q(q, CALL) do { \
         if ((q) <= 8) { CALL(64, 8); } else if ((q) <= 16) { CALL(64, 16); } \
         else if ((q) <= 20) { CALL(64, 20); } else if ((q) <= 32) { CALL(64, 32); } \

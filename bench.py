@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--q', type=int, default=20)
     ap.add_argument('--n', type=int, default=310)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-hessian', action='store_true', help='skip the Hessian throughput leg (profile runs: keeps the kernel statistics to the timed path)')
     ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' only for rehearsing N > 1 on one GPU")
     ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses GPU 0')
     args = ap.parse_args()
@@ -177,16 +178,18 @@ def main():
                     'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
         # Hessian throughput of the same model and candidates (second half of the metric), outside
         # the timed region: a few calls on a slice of this rank's candidates
-        hb = min(B, 2048)
-        gp.hessian(X_local[:hb])
-        torch.cuda.synchronize()
-        th = time.perf_counter()
-        for _ in range(3):
-            _, hst = gp.hessian(X_local[:hb])
-        torch.cuda.synchronize()
-        th = (time.perf_counter() - th) / 3
-        hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
-                   'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item())}
+        hessian = None
+        if not args.no_hessian:
+            hb = min(B, 2048)
+            gp.hessian(X_local[:hb])
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            for _ in range(3):
+                _, hst = gp.hessian(X_local[:hb])
+            torch.cuda.synchronize()
+            th = (time.perf_counter() - th) / 3
+            hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
+                       'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item())}
         cpu = None
         if not args.no_cpu_baseline:
             v, done, secs = cpu_baseline(model, X_local[:24].cpu().numpy())

@@ -1,7 +1,7 @@
 """GPU parity across the solver's size classes and input shapes.
 
 The device solver has one register-path instance per padded size (8, 16, 20, 32; exact and padded
-variants of each) and an LDS path for q > 32; the kernels around it are specialised for d = 6 and
+variants of each) and a wide path (256 threads per candidate) for q > 32; the kernels around it are specialised for d = 6 and
 generic otherwise.  Every class is run here through the C ABI and checked with the
 solver-independent KKT certificate (full reference-form M and Y), against the CPU restatement of
 the reduced problem, and -- for the gradient -- against d<Omega(X), M>/dX of the oracle's GP.
@@ -47,17 +47,17 @@ def _check_batch(om, dm, Xs, cert_tol=1e-8):
     return value, grad
 
 
-@pytest.mark.parametrize('q', [2, 7, 8, 9, 16, 17, 19, 21, 32, 33, 40])
+@pytest.mark.parametrize('q', [2, 7, 8, 9, 16, 17, 19, 21, 32, 33, 40, 49, 64])
 def test_value_grad_size_classes(cuda, q):
     """One padded and one exact member of every register-path class, both sides of the switch to
-    the LDS path, odd and even q."""
+    the wide path (several waves per candidate), odd and even q, and the largest q accepted."""
     om, dm = _mk(60)
     Xs = np.random.RandomState(31 + q).uniform(-.5, .5, (3, q, 6))
     _check_batch(om, dm, Xs)
 
 
 def test_value_grad_cfg3_shape(cuda):
-    """The largest configuration of the benchmark table: n = 1000, q = 50, d = 10 (LDS path,
+    """The largest configuration of the benchmark table: n = 1000, q = 50, d = 10 (wide path,
     generic-dimension kernels)."""
     om, dm = _mk(1000, d=10, lengthscale=0.8)
     Xs = np.random.RandomState(41).uniform(-.5, .5, (2, 50, 10))
@@ -121,16 +121,15 @@ def test_ragged_and_empty_batches(cuda, B):
 
 def test_sdp_batched_mixed_conditioning(cuda):
     """Stand-alone SDP on generic (non-GP) inputs of several sizes, including nearly singular
-    covariance blocks and widely spread means.  The register path (q <= 32) works on a square
-    root of the covariance and keeps its accuracy down to a ridge of 1e-8; the LDS path
-    diagonalises the covariance-sized matrix itself and is exercised with a ridge of 1e-5."""
+    covariance blocks and widely spread means.  Both solver paths work on a square root of the
+    covariance (one-sided Jacobi) and keep their accuracy down to a ridge of 1e-8."""
     from bayesian_optimization_amd import sdp_batched
     rs = np.random.RandomState(59)
-    for k in (3, 8, 20, 33):
+    for k in (3, 8, 20, 33, 64):
         oms, fms = [], []
         for trial in range(6):
             tmp = rs.randn(k, k) * (10.0 ** rs.uniform(-2, 1))
-            sigma = tmp.dot(tmp.T) + ((1e-8 if k <= 32 else 1e-5) if trial % 2 else 1e-2) * np.eye(k)
+            sigma = tmp.dot(tmp.T) + (1e-8 if trial % 2 else 1e-2) * np.eye(k)
             mu = rs.randn(k) * (10.0 ** rs.uniform(-1, 1))
             o = np.zeros((k + 1, k + 1))
             o[:k, :k] = sigma + np.outer(mu, mu)
