@@ -101,6 +101,146 @@ __device__ __forceinline__ void posterior_moments(const SdpWork w, const KernPar
     __syncthreads();
 }
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// The same moments for the one-wave kernels (q <= Q <= 32) on the matrix pipe: with E = [A rows;
+// v] ((q+1) x npad), E E^T holds A A^T and A v.  v_mfma_f64_16x16x4 takes, per lane, one entry
+// of each operand: lane l supplies row (l & 15) of a 16-row tile at one of four k positions
+// (l >> 4).  A sum over k may visit k in any order, so lane l loads four consecutive doubles of
+// its row per 16 columns (16 rows x 128 B per load instruction, every fetched line used whole)
+// and feeds them to four successive MFMAs.  No LDS staging; the co-resident wave's vector
+// arithmetic runs while the matrix pipe works.
+template <int Q>
+__device__ __forceinline__ void posterior_moments_mfma(const SdpWork w, const KernParams& kp, double noise,
+                                                       int npad, size_t astride,
+                                                       const double* __restrict__ Arows,
+                                                       const double* __restrict__ v,
+                                                       const lds_f64* xq, lds_f64* mu) {
+    constexpr int NR = (Q + 1 + 15) / 16;              // row tiles of E
+    constexpr int NTILE = NR * (NR + 1) / 2;           // lower block triangle of E E^T
+    const int lane = threadIdx.x;
+    const int q = w.q, LD = w.LD, d = kp.d;
+    const int li = lane & 15, kg = lane >> 4;
+    const double* src[NR];
+    bool valid[NR];
+#pragma unroll
+    for (int I = 0; I < NR; ++I) {
+        const int r = 16 * I + li;
+        valid[I] = r <= q;
+        src[I] = (r < q ? Arows + (size_t)r * astride : v) + 4 * kg;
+    }
+    double4_t acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double4_t cur[NR], nxt[NR];
+#pragma unroll
+    for (int I = 0; I < NR; ++I) {
+        cur[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        nxt[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if (valid[I]) cur[I] = *reinterpret_cast<const double4_t*>(src[I]);
+    }
+    const int ns = npad / 16;
+    for (int s = 0; s < ns; ++s) {
+        if (s + 1 < ns) {
+#pragma unroll
+            for (int I = 0; I < NR; ++I)
+                if (valid[I]) nxt[I] = *reinterpret_cast<const double4_t*>(src[I] + 16 * (s + 1));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int t = 0;
+#pragma unroll
+            for (int I = 0; I < NR; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J, ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][u], cur[J][u], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int I = 0; I < NR; ++I) cur[I] = nxt[I];
+    }
+    // accumulator g of lane l is entry (row (l >> 4) + 4 g, column l & 15) of its tile
+    {
+        int t = 0;
+#pragma unroll
+        for (int I = 0; I < NR; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J, ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int i = 16 * I + kg + 4 * g, j = 16 * J + li;
+                    if (i < q && j <= i) w.S[i * LD + j] = acc[t][g];
+                    else if (i == q && j < q) mu[j] = acc[t][g];
+                }
+    }
+    __syncthreads();
+    for (int e = lane; e < q * q; e += 64) {
+        const int i = e / q, j = e - i * q;
+        if (j > i) continue;
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[i * d + l] - xq[j * d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        const double val = kp.variance * k0 - w.S[i * LD + j] + (i == j ? noise : 0.0);
+        w.S[i * LD + j] = val;
+        w.S[j * LD + i] = val;
+    }
+    __syncthreads();
+}
+
+// Z[a, k] = -sum_b N[a][b] A[b][k] for the one-wave kernels, on the matrix pipe: N (w.H) is the
+// left operand, held in registers for the whole pass; each 16-column tile of the candidate's A
+// rows is loaded once (128 B per row and load instruction) and its Z tile stored the same way.
+template <int Q>
+__device__ __forceinline__ void zmat_mfma(const SdpWork w, int npad, size_t astride,
+                                          const double* __restrict__ Arows, double* __restrict__ Zrows) {
+    constexpr int NRZ = (Q + 15) / 16, NKZ = (Q + 3) / 4;
+    const int lane = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const int li = lane & 15, kg = lane >> 4;
+    double nop[NRZ][NKZ];
+#pragma unroll
+    for (int I = 0; I < NRZ; ++I)
+#pragma unroll
+        for (int s = 0; s < NKZ; ++s) {
+            const int i = 16 * I + li, b = 4 * s + kg;
+            const bool in = i < q && b < q;
+            const double h = w.H[(in ? i : 0) * LD + (in ? b : 0)];
+            nop[I][s] = in ? h : 0.0;
+        }
+    const double* brow[NKZ];
+    bool bval[NKZ];
+#pragma unroll
+    for (int s = 0; s < NKZ; ++s) {
+        const int b = 4 * s + kg;
+        bval[s] = b < q;
+        brow[s] = Arows + (size_t)(bval[s] ? b : 0) * astride + li;
+    }
+#pragma unroll 2
+    for (int c0 = 0; c0 < npad; c0 += 16) {
+        double bop[NKZ];
+#pragma unroll
+        for (int s = 0; s < NKZ; ++s) { const double x = brow[s][c0]; bop[s] = bval[s] ? x : 0.0; }
+        double4_t acc[NRZ];
+#pragma unroll
+        for (int I = 0; I < NRZ; ++I) acc[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < NKZ; ++s)
+#pragma unroll
+            for (int I = 0; I < NRZ; ++I)
+                acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(nop[I][s], bop[s], acc[I], 0, 0, 0);
+#pragma unroll
+        for (int I = 0; I < NRZ; ++I)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 16 * I + kg + 4 * g;
+                if (row < q) Zrows[(size_t)row * npad + c0 + li] = -acc[I][g];
+            }
+    }
+}
+
 // LDS of the per-candidate kernels: the solver region (with the A-row staging buffers Ac [q][CH+1]
 // and vc [CH] overlaid on everything behind w.H, which is idle while rows are staged), then
 // mu [q+2] and xq [q*d].  `full`: six-matrix layout (sensitivity kernels), else three.
@@ -126,7 +266,8 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     const int tid = threadIdx.x, b = blockIdx.x, k_ = q + 1, LD = w.LD;
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
-    posterior_moments<T>(w, kp, noise, n, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu, Ac, vc);
+    if constexpr (Q > 0) posterior_moments_mfma<Q>(w, kp, noise, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu);
+    else posterior_moments<T>(w, kp, noise, n, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu, Ac, vc);
     double* om = omega + (size_t)b * k_ * k_;
     for (int e = tid; e < k_ * k_; e += T) {
         const int i = e / k_, j = e - i * k_;
@@ -161,7 +302,8 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
     const double* Arows = A + (size_t)b * a_cand_stride;
-    posterior_moments<T>(w, kp, noise, n, npad, a_row_stride, Arows, v, xq, mu, Ac, vc);
+    if constexpr (Q > 0) posterior_moments_mfma<Q>(w, kp, noise, npad, a_row_stride, Arows, v, xq, mu);
+    else posterior_moments<T>(w, kp, noise, n, npad, a_row_stride, Arows, v, xq, mu, Ac, vc);
     if (tid < q) w.dl[tid] = mu[tid] - fmin;
     __syncthreads();
     double g = 0.0;
@@ -184,22 +326,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     }
     // Z[a, k] = sum_b M11[a, b] A[b, k] with M11 = -N (w.H)
     if constexpr (Q > 0) {
-        // lane k keeps column k of the candidate's A rows in registers; N is read as broadcasts
-        for (int col = tid; col < npad; col += T) {
-            double av[Q];
-#pragma unroll
-            for (int bb = 0; bb < Q; ++bb) av[bb] = (bb < q) ? Arows[(size_t)bb * a_row_stride + col] : 0.0;
-#pragma unroll 2
-            for (int a = 0; a < q; ++a) {
-                double s = 0.0;
-#pragma unroll
-                for (int bb = 0; bb < Q; ++bb) {
-                    const double h = w.H[a * LD + bb];      // beyond q: inside the LDS allocation, discarded
-                    s -= ((bb < q) ? h : 0.0) * av[bb];
-                }
-                Zrows[(size_t)a * npad + col] = s;
-            }
-        }
+        zmat_mfma<Q>(w, npad, a_row_stride, Arows, Zrows);
     } else {
         const int nchunks = npad / CH;
         for (int c = 0; c < nchunks; ++c) {
