@@ -448,6 +448,62 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
     }
 }
 
+// ---- gradient, finishing step after the fused GEMM + contraction -----------------------------------
+// Gpart [OEI_GG_SPLIT][nrows][d+1] holds the n-length sums of k_grad's chunk loop; what is left is
+// per candidate: grad[a][l] = (x_al G[a][d] - G[a][l]) / ls_l^2 + the self-covariance terms, and
+// the mutual-duplicate flag (oei.py:190).
+__global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nrows,
+                                                 const double* __restrict__ Xq,
+                                                 const double* __restrict__ Gpart,
+                                                 const double* __restrict__ M11_in,
+                                                 double* __restrict__ grad, int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int T = 64;
+    const int d = kp.d, dp = d + 1;
+    lds_f64* xq = (lds_f64*)sm;               // [q][d]
+    lds_f64* M11 = xq + q * d;                // [q][q]
+    lds_f64* Gs = M11 + q * q;                // [q][q]     2 var kappa'(t_ab)
+    lds_f64* Gl = Gs + q * q;                 // [q][d+1]
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int e = tid; e < q * d; e += T) xq[e] = Xq[(size_t)b * q * d + e];
+    for (int e = tid; e < q * q; e += T) M11[e] = M11_in[(size_t)b * q * q + e];
+    for (int e = tid; e < q * dp; e += T) {
+        double acc = 0.0;
+        for (int sp = 0; sp < OEI_GG_SPLIT; ++sp) acc += Gpart[((size_t)sp * nrows + (size_t)b * q) * dp + e];
+        Gl[e] = acc;
+    }
+    __syncthreads();
+    int flag = 0;
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, bb = e - a * q;
+        double t = 0.0;
+        bool same = true;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - xq[bb * d + l];
+            t += df * df * kp.inv_ls2[l];
+            same = same && (rint(xq[a * d + l] / kp.ls[l] * 100.0) == rint(xq[bb * d + l] / kp.ls[l] * 100.0));
+        }
+        double k0, k1, k2;
+        kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        Gs[e] = (a == bb) ? 0.0 : 2.0 * kp.variance * k1;
+        if (a != bb && same) flag = 1;
+    }
+    __syncthreads();
+    for (int e = tid; e < q * d; e += T) {
+        const int a = e / d, l = e - a * d;
+        double gval = (xq[a * d + l] * Gl[a * dp + d] - Gl[a * dp + l]) * kp.inv_ls2[l];
+        double s = 0.0;
+        for (int bb = 0; bb < q; ++bb)
+            s += M11[a * q + bb] * Gs[a * q + bb] * (xq[a * d + l] - xq[bb * d + l]);
+        gval += 2.0 * s * kp.inv_ls2[l];
+        grad[(size_t)b * q * d + e] = gval;
+    }
+    if (flags) {
+        flag = __syncthreads_or(flag);
+        if (tid == 0 && flag) flags[b] = 1;          // zeroed by the caller; the Gram kernel may have set it
+    }
+}
+
 // ---- predict_f: mean_i = A_i . v, var_i = k(x_i,x_i) - |A_i|^2 (one wave per point) ---------------
 __global__ void k_predict(KernParams kp, int npad, const double* __restrict__ A,
                           const double* __restrict__ v, double* __restrict__ mean,
@@ -588,7 +644,7 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d;
     const size_t rows = (size_t)B * q, rows_pad = round_up(rows, 64);
-    const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q) * sizeof(double);
+    const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q + (size_t)OEI_GG_SPLIT * B * q * (d + 1)) * sizeof(double);
     const bool prof = m->profile != 0;
     rc = oei_ws_reserve(m, rows_pad, aux_bytes);
     if (rc) return rc;
@@ -613,17 +669,28 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
         OEI_HIP_CHECK(hipMemsetAsync(m->ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[3], st));
-    rc = oei_launch_gemm_nt(m->ws0, m->LinvT, m->ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
-    if (rc) return rc;
-    if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
-    // four waves per candidate split its points four ways and overlap their memory latencies
-    // (measured at q = 20: 0.29 ms with one wave, 0.19 ms with four, 0.26 ms with eight)
-    if (q <= 4) {
-        if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
-        hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
+    if (d + 1 <= OEI_GG_MAX_DP) {
+        // W = Z L^-1 contracted with K1 and X inside the GEMM; a small per-candidate kernel finishes
+        double* Gpart = M11_buf + (size_t)B * q * q;
+        rc = oei_launch_gemm_grad(m, m->ws0, m->ws2, p_buf, Gpart, rows, rows_pad, st);
+        if (rc) return rc;
+        if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
+        const size_t ldsf = ((size_t)q * d + 2 * (size_t)q * q + (size_t)q * (d + 1)) * sizeof(double);
+        if ((rc = set_lds(k_grad_fin, ldsf))) return rc;
+        hipLaunchKernelGGL(k_grad_fin, dim3(B), dim3(64), ldsf, st, m->kp, q, rows, X, Gpart, M11_buf, grad, flags);
     } else {
-        if ((rc = set_lds(k_grad<256>, ldsg))) return rc;
-        hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
+        rc = oei_launch_gemm_nt(m->ws0, m->LinvT, m->ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
+        if (rc) return rc;
+        if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
+        // four waves per candidate split its points four ways and overlap their memory latencies
+        // (measured at q = 20: 0.29 ms with one wave, 0.19 ms with four, 0.26 ms with eight)
+        if (q <= 4) {
+            if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
+            hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
+        } else {
+            if ((rc = set_lds(k_grad<256>, ldsg))) return rc;
+            hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
+        }
     }
     OEI_HIP_CHECK(hipGetLastError());
     if (prof) { OEI_HIP_CHECK(hipEventRecord(m->ev[5], st)); m->ev_valid = 1; }

@@ -339,6 +339,163 @@ int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows
     return OEI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second GEMM fused with the n-length contraction of the gradient.  W = Z L^-1 is needed only in
+//   Gacc[r][l] = sum_k (p_r alpha_k - 2 W[r,k]) K1[r,k] X[k,l]   (l < d),   Gacc[r][d] = sum_k (...)
+// (r = candidate point, k = training point), so every 64 x 64 tile of W is contracted with its
+// K1 tile and 64 rows of X while it is still in the MFMA accumulators, and W never travels to
+// memory.  A workgroup owns a 64-row block and one of GG_SPLIT subsets of the column tiles (the
+// subsets carry about the same number of K steps: the K range of tile j starts at its diagonal);
+// each subset writes its own partial sums, added by the finishing kernel.
+// Accumulator g of lane l holds W[row (l >> 4) + 4 g][column l & 15] of its 16 x 16 tile: the lanes
+// of one DPP row (16 lanes) share their rows, so the final reduction over columns is four DPP
+// steps.
+#define GG_SPLIT OEI_GG_SPLIT
+template <int CTRL>
+__device__ __forceinline__ double gg_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int DPM>
+__global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__ Z,
+                                                   const double* __restrict__ LinvT,
+                                                   const double* __restrict__ K1,
+                                                   const double* __restrict__ alpha,
+                                                   const double* __restrict__ Xtrain,
+                                                   const double* __restrict__ pvec,
+                                                   double* __restrict__ Gpart, int npad, int d,
+                                                   unsigned nrb, size_t nrows) {
+    __shared__ __attribute__((aligned(16))) double As[2 * GM_BM * GM_LDS];
+    __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
+    __shared__ double Xs[64 * (DPM + 1)];
+    __shared__ double Gs[64 * (DPM + 1)];      // Gacc of this workgroup's rows; entry (row, l) has one owner lane
+    const int nt = npad / GM_BN, dp = d + 1;
+    const unsigned split = blockIdx.x % GG_SPLIT, rb = blockIdx.x / GG_SPLIT;
+    if (rb >= nrb) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const size_t r0 = (size_t)rb * GM_BM;
+    const int srow = tid >> 2, scol = (tid & 3) * 4;
+    const double* Ag = Z + (r0 + srow) * npad + scol;
+    size_t rows[4];
+    double pr[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const size_t r = r0 + wave * 16 + kg + 4 * g;
+        rows[g] = r < nrows ? r : nrows - 1;          // padding rows read a valid row, never stored
+        pr[g] = pvec[rows[g]];
+    }
+    for (int e = tid; e < 64 * (DPM + 1); e += 256) Gs[e] = 0.0;
+
+    for (int j = 0; j < nt; ++j) {
+        const int jm = j & 3;
+        if ((unsigned)((jm == 0 || jm == 3) ? 0 : 1) != split) continue;
+        const int j0 = j * GM_BN;
+        const double* Bg = LinvT + (size_t)(j0 + srow) * npad + scol;
+        double4_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        double2 a0, a1, b0, b1;
+        a0 = *reinterpret_cast<const double2*>(Ag + j0);
+        a1 = *reinterpret_cast<const double2*>(Ag + j0 + 2);
+        b0 = *reinterpret_cast<const double2*>(Bg + j0);
+        b1 = *reinterpret_cast<const double2*>(Bg + j0 + 2);
+        __syncthreads();                 // the previous tile's readers of As/Bs/Xs are done
+        for (int e = tid; e < 64 * dp; e += 256) {
+            const int k = e / dp, l = e - k * dp;
+            Xs[k * (DPM + 1) + l] = (l < d) ? Xtrain[(size_t)(j0 + k) * d + l] : 1.0;
+        }
+        int buf = 0;
+        for (int k0 = j0; k0 < npad; k0 += GM_BK) {
+            double* as = As + buf * (GM_BM * GM_LDS);
+            double* bs = Bs + buf * (GM_BN * GM_LDS);
+            as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
+            as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
+            bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
+            bs[srow * GM_LDS + scol + 2] = b1.x; bs[srow * GM_LDS + scol + 3] = b1.y;
+            __syncthreads();
+            if (k0 + GM_BK < npad) {
+                a0 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK);
+                a1 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK + 2);
+                b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
+                b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
+            }
+#pragma unroll
+            for (int ks = 0; ks < GM_BK / 4; ++ks) {
+                const double av = as[(wave * 16 + li) * GM_LDS + ks * 4 + kg];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + kg];
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+            buf ^= 1;
+        }
+        // contraction of the W tile (Xs was published by the barriers of the K loop), two of the
+        // lane's four rows at a time to keep the register count at four waves per SIMD
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double P[2][DPM];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int l = 0; l < DPM; ++l) P[g][l] = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int col = 16 * t + li;
+                const double al = alpha[j0 + col];
+                double xv[DPM];
+#pragma unroll
+                for (int l = 0; l < DPM; ++l) xv[l] = (l < dp) ? Xs[col * (DPM + 1) + l] : 0.0;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const double k1 = K1[rows[2 * h + g] * npad + j0 + col];
+                    const double ck = fma(pr[2 * h + g], al, -2.0 * acc[t][2 * h + g]) * k1;
+#pragma unroll
+                    for (int l = 0; l < DPM; ++l) P[g][l] = fma(ck, xv[l], P[g][l]);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int rl = wave * 16 + kg + 4 * (2 * h + g);
+#pragma unroll
+                for (int l = 0; l < DPM; ++l) {
+                    double v = P[g][l];
+                    v += gg_dpp<0xB1>(v);        // quad_perm [1,0,3,2]
+                    v += gg_dpp<0x4E>(v);        // quad_perm [2,3,0,1]
+                    v += gg_dpp<0x141>(v);       // row_half_mirror
+                    v += gg_dpp<0x140>(v);       // row_mirror
+                    if (li == l) Gs[rl * (DPM + 1) + l] += v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * dp; e += 256) {
+        const int rl = e / dp, l = e - rl * dp;
+        const size_t r = r0 + rl;
+        if (r < nrows) Gpart[((size_t)split * nrows + r) * dp + l] = Gs[rl * (DPM + 1) + l];
+    }
+}
+
+// Gpart [GG_SPLIT][nrows][d+1]; returns OEI_ERR_ARG when d + 1 exceeds the register budget of the
+// fused kernel (the caller then takes the two-kernel route).
+int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, const double* pvec,
+                         double* Gpart, size_t nrows, size_t rows_pad, hipStream_t st) {
+    const unsigned nrb = (unsigned)(rows_pad / GM_BM);
+    dim3 grid(nrb * GG_SPLIT);
+    if (m->d + 1 <= 8)
+        hipLaunchKernelGGL(k_gemm_grad<8>, grid, dim3(256), 0, st, Z, m->LinvT, K1, m->alpha, m->X, pvec, Gpart, m->npad, m->d, nrb, nrows);
+    else if (m->d + 1 <= 12)
+        hipLaunchKernelGGL(k_gemm_grad<12>, grid, dim3(256), 0, st, Z, m->LinvT, K1, m->alpha, m->X, pvec, Gpart, m->npad, m->d, nrb, nrows);
+    else
+        return OEI_ERR_ARG;
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
 // G_b = E_b E_b^T for every candidate: lower block-triangle of 64x64 tiles, tile index t of
 // blockIdx.y enumerates (I >= J).  E [B*RP, npad], G [B, RP, RP].
 __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
