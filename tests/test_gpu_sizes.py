@@ -65,9 +65,11 @@ def test_value_grad_cfg3_shape(cuda):
 
 
 @pytest.mark.parametrize('n,d,kind,fm,ls', [(20, 3, ogp.KERNEL_RBF, 0, 0.3),
-                                             (80, 10, ogp.KERNEL_MATERN32, 1, 0.6)])
+                                             (80, 10, ogp.KERNEL_MATERN32, 1, 0.6),
+                                             (70, 13, ogp.KERNEL_MATERN32, 1, 0.9)])
 def test_other_dimensions_value_grad_hessian(cuda, n, d, kind, fm, ls):
-    """Dimensions other than 6 (generic-dimension kernels).  The d = 3 model is kept small: with
+    """Dimensions other than 6 (generic-dimension kernels; d = 13 is beyond the register budget
+    of the fused GEMM + gradient contraction and takes the two-kernel route).  The d = 3 model is kept small: with
     many points the posterior covariance drops to the noise level and the oracle's first-order
     solve (the checker, not the device path) no longer converges."""
     om, dm = _mk(n, d=d, kind=kind, floor_mode=fm, lengthscale=ls)
