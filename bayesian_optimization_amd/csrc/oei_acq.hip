@@ -449,10 +449,10 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
 }
 
 // ---- gradient, finishing step after the fused GEMM + contraction -----------------------------------
-// Gpart [OEI_GG_SPLIT][nrows][d+1] holds the n-length sums of k_grad's chunk loop; what is left is
+// Gpart [nsplit][nrows][d+1] holds the n-length sums of k_grad's chunk loop; what is left is
 // per candidate: grad[a][l] = (x_al G[a][d] - G[a][l]) / ls_l^2 + the self-covariance terms, and
 // the mutual-duplicate flag (oei.py:190).
-__global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nrows,
+__global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nrows, int nsplit,
                                                  const double* __restrict__ Xq,
                                                  const double* __restrict__ Gpart,
                                                  const double* __restrict__ M11_in,
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nr
     for (int e = tid; e < q * q; e += T) M11[e] = M11_in[(size_t)b * q * q + e];
     for (int e = tid; e < q * dp; e += T) {
         double acc = 0.0;
-        for (int sp = 0; sp < OEI_GG_SPLIT; ++sp) acc += Gpart[((size_t)sp * nrows + (size_t)b * q) * dp + e];
+        for (int sp = 0; sp < nsplit; ++sp) acc += Gpart[((size_t)sp * nrows + (size_t)b * q) * dp + e];
         Gl[e] = acc;
     }
     __syncthreads();
@@ -644,7 +644,7 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d;
     const size_t rows = (size_t)B * q, rows_pad = round_up(rows, 64);
-    const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q + (size_t)OEI_GG_SPLIT * B * q * (d + 1)) * sizeof(double);
+    const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q + (size_t)(m->npad / 64) * B * q * (d + 1)) * sizeof(double);
     const bool prof = m->profile != 0;
     rc = oei_ws_reserve(m, rows_pad, aux_bytes);
     if (rc) return rc;
@@ -677,7 +677,7 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
         if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
         const size_t ldsf = ((size_t)q * d + 2 * (size_t)q * q + (size_t)q * (d + 1)) * sizeof(double);
         if ((rc = set_lds(k_grad_fin, ldsf))) return rc;
-        hipLaunchKernelGGL(k_grad_fin, dim3(B), dim3(64), ldsf, st, m->kp, q, rows, X, Gpart, M11_buf, grad, flags);
+        hipLaunchKernelGGL(k_grad_fin, dim3(B), dim3(64), ldsf, st, m->kp, q, rows, m->npad / 64, X, Gpart, M11_buf, grad, flags);
     } else {
         rc = oei_launch_gemm_nt(m->ws0, m->LinvT, m->ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
         if (rc) return rc;

@@ -118,8 +118,7 @@ int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const d
 int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st);
 // C[r, j] = sum_k A[r, k] * Bm[j, k], all [*, npad] row-major; `lower` != 0 means Bm is lower
 // triangular (k <= j), else upper triangular (k >= j).
-// Fused W = Z L^-1 and gradient contraction; Gpart [OEI_GG_SPLIT][nrows][d+1] partial sums.
-#define OEI_GG_SPLIT 2
+// Fused W = Z L^-1 and gradient contraction; Gpart [npad / 64][nrows][d+1] partial sums.
 #define OEI_GG_MAX_DP 12
 int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, const double* pvec,
                          double* Gpart, size_t nrows, size_t rows_pad, hipStream_t st);

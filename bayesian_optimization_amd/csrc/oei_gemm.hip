@@ -344,13 +344,11 @@ int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows
 //   Gacc[r][l] = sum_k (p_r alpha_k - 2 W[r,k]) K1[r,k] X[k,l]   (l < d),   Gacc[r][d] = sum_k (...)
 // (r = candidate point, k = training point), so every 64 x 64 tile of W is contracted with its
 // K1 tile and 64 rows of X while it is still in the MFMA accumulators, and W never travels to
-// memory.  A workgroup owns a 64-row block and one of GG_SPLIT subsets of the column tiles (the
-// subsets carry about the same number of K steps: the K range of tile j starts at its diagonal);
-// each subset writes its own partial sums, added by the finishing kernel.
+// memory.  A workgroup owns one 64 x 64 tile (the K range of column tile j starts at its diagonal)
+// and writes that tile's partial sums; the finishing kernel adds the npad / 64 partials of a row.
 // Accumulator g of lane l holds W[row (l >> 4) + 4 g][column l & 15] of its 16 x 16 tile: the lanes
 // of one DPP row (16 lanes) share their rows, so the final reduction over columns is four DPP
 // steps.
-#define GG_SPLIT OEI_GG_SPLIT
 template <int CTRL>
 __device__ __forceinline__ double gg_dpp(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
@@ -371,9 +369,13 @@ __global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__
     __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
     __shared__ double Xs[64 * (DPM + 1)];
     __shared__ double Gs[64 * (DPM + 1)];      // Gacc of this workgroup's rows; entry (row, l) has one owner lane
+    // one column tile per workgroup; the tiles of one 64-row block of Z get consecutive slots of
+    // the same XCD (as in k_gemm_nt), so they run together and share the block through that L2
     const int nt = npad / GM_BN, dp = d + 1;
-    const unsigned split = blockIdx.x % GG_SPLIT, rb = blockIdx.x / GG_SPLIT;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const size_t rb = (size_t)(slot / nt) * 8 + xcd;
     if (rb >= nrb) return;
+    const unsigned split = slot % nt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const size_t r0 = (size_t)rb * GM_BM;
@@ -389,10 +391,8 @@ __global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__
     }
     for (int e = tid; e < 64 * (DPM + 1); e += 256) Gs[e] = 0.0;
 
-    for (int j = 0; j < nt; ++j) {
-        const int jm = j & 3;
-        if ((unsigned)((jm == 0 || jm == 3) ? 0 : 1) != split) continue;
-        const int j0 = j * GM_BN;
+    {
+        const int j0 = (int)split * GM_BN;
         const double* Bg = LinvT + (size_t)(j0 + srow) * npad + scol;
         double4_t acc[4];
 #pragma unroll
@@ -480,12 +480,12 @@ __global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__
     }
 }
 
-// Gpart [GG_SPLIT][nrows][d+1]; returns OEI_ERR_ARG when d + 1 exceeds the register budget of the
+// Gpart [npad / 64][nrows][d+1]; returns OEI_ERR_ARG when d + 1 exceeds the register budget of the
 // fused kernel (the caller then takes the two-kernel route).
 int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, const double* pvec,
                          double* Gpart, size_t nrows, size_t rows_pad, hipStream_t st) {
-    const unsigned nrb = (unsigned)(rows_pad / GM_BM);
-    dim3 grid(nrb * GG_SPLIT);
+    const unsigned nrb = (unsigned)(rows_pad / GM_BM), nt = (unsigned)(m->npad / GM_BN);
+    dim3 grid(((nrb + 7) / 8) * 8 * nt);
     if (m->d + 1 <= 8)
         hipLaunchKernelGGL(k_gemm_grad<8>, grid, dim3(256), 0, st, Z, m->LinvT, K1, m->alpha, m->X, pvec, Gpart, m->npad, m->d, nrb, nrows);
     else if (m->d + 1 <= 12)
