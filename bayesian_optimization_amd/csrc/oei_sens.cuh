@@ -138,75 +138,68 @@ __device__ __forceinline__ void sens_sync() {
     }
 }
 
-// The same product for one wave, register-blocked: a lane owns a BH x BW block of C, so a group
-// of BH + BW LDS reads feeds BH * BW multiply-adds (the element-per-lane form needs two reads per
-// multiply-add and is bound by LDS issue and latency).  Rows and columns past q are clamped for
-// the reads and not stored.
-template <int BH, int BW, bool TA, bool TB, bool SC>
-__device__ __forceinline__ void wave_mm_blk(int lane, int q, int LD, const lds_f64* A, const lds_f64* B,
-                                            lds_f64* C, const lds_f64* sc) {
-    const int nrb = (q + BH - 1) / BH, ncb = (q + BW - 1) / BW;
-    const int sa = TA ? LD : 1, sb = TB ? 1 : LD;
-    for (int blk = lane; blk < nrb * ncb; blk += 64) {
-        const int ib = blk / ncb, jb = blk - ib * ncb;
-        int ao[BH], bo[BW];
+// The same product for one wave on the matrix pipe (q <= 32): v_mfma_f64_16x16x4 takes one entry of
+// each operand per lane -- lane l supplies A'[16 I + (l & 15)][4 s + (l >> 4)] and
+// B'[4 s + (l >> 4)][16 J + (l & 15)] -- so a q = 20 product is 20 LDS reads, 20 MFMAs and 16
+// stores per lane instead of about 100 reads and 125 multiply-adds, and the vector unit stays free
+// for the wave that shares the SIMD.  Entries past q are supplied as zeros.
+typedef double sens_double4 __attribute__((ext_vector_type(4)));
+template <int NT, bool TA, bool TB, bool SC>
+__device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_f64* A, const lds_f64* B,
+                                             lds_f64* C, const lds_f64* sc) {
+    const int li = lane & 15, kg = lane >> 4;
+    sens_double4 acc[NT][NT];
 #pragma unroll
-        for (int r = 0; r < BH; ++r) { const int i = min(ib * BH + r, q - 1); ao[r] = TA ? i : i * LD; }
+    for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int c = 0; c < BW; ++c) { const int j = min(jb * BW + c, q - 1); bo[c] = TB ? j * LD : j; }
-        double acc[BH][BW];
+        for (int J = 0; J < NT; ++J) acc[I][J] = (sens_double4){0.0, 0.0, 0.0, 0.0};
+    const int ks = (q + 3) >> 2;
+#pragma unroll 2
+    for (int s = 0; s < ks; ++s) {
+        const int k = 4 * s + kg;
+        const bool kin = k < q;
+        const int kc = kin ? k : 0;
+        double av[NT], bv[NT];
+        const double scale = SC ? sc[kc] : 1.0;
 #pragma unroll
-        for (int r = 0; r < BH; ++r)
-#pragma unroll
-            for (int c = 0; c < BW; ++c) acc[r][c] = 0.0;
-        int k = 0;
-        for (; k + 4 <= q; k += 4) {
-            double av[4][BH], bv[4][BW], sv4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int r = 0; r < BH; ++r) av[u][r] = A[ao[r] + (k + u) * sa];
-#pragma unroll
-                for (int c = 0; c < BW; ++c) bv[u][c] = B[bo[c] + (k + u) * sb];
-                if (SC) sv4[u] = sc[k + u];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                for (int r = 0; r < BH; ++r) {
-                    const double a = SC ? av[u][r] * sv4[u] : av[u][r];
-#pragma unroll
-                    for (int c = 0; c < BW; ++c) acc[r][c] = fma(a, bv[u][c], acc[r][c]);
-                }
-            }
-            SDP_READS_FIRST(4 * (BH + BW) + (SC ? 4 : 0), 4 * BH * BW + (SC ? 4 * BH : 0));
-        }
-        for (; k < q; ++k) {
-            double av[BH], bv[BW];
-#pragma unroll
-            for (int r = 0; r < BH; ++r) av[r] = A[ao[r] + k * sa] * (SC ? sc[k] : 1.0);
-#pragma unroll
-            for (int c = 0; c < BW; ++c) bv[c] = B[bo[c] + k * sb];
-#pragma unroll
-            for (int r = 0; r < BH; ++r)
-#pragma unroll
-                for (int c = 0; c < BW; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+        for (int I = 0; I < NT; ++I) {
+            const int i = 16 * I + li;
+            const bool in = kin && i < q;
+            const int ic = in ? i : 0;
+            const double x = A[TA ? kc * LD + ic : ic * LD + kc];
+            av[I] = in ? (SC ? x * scale : x) : 0.0;
         }
 #pragma unroll
-        for (int r = 0; r < BH; ++r)
+        for (int J = 0; J < NT; ++J) {
+            const int j = 16 * J + li;
+            const bool in = kin && j < q;
+            const int jc = in ? j : 0;
+            const double x = B[TB ? jc * LD + kc : kc * LD + jc];
+            bv[J] = in ? x : 0.0;
+        }
 #pragma unroll
-            for (int c = 0; c < BW; ++c)
-                if (ib * BH + r < q && jb * BW + c < q) C[(ib * BH + r) * LD + jb * BW + c] = acc[r][c];
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[I][J], 0, 0, 0);
     }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = 0; J < NT; ++J)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 16 * I + kg + 4 * g, j = 16 * J + li;
+                if (i < q && j < q) C[i * LD + j] = acc[I][J][g];
+            }
 }
 
 template <int T, bool WAVE, bool TA, bool TB, bool SC>
 __device__ __forceinline__ void sens_mm(int tid, int q, int LD, const lds_f64* A, const lds_f64* B,
                                         lds_f64* C, const lds_f64* sc = nullptr) {
     if constexpr (WAVE) {
-        if (q <= 16) wave_mm_blk<2, 2, TA, TB, SC>(tid, q, LD, A, B, C, sc);
-        else if (q <= 20) wave_mm_blk<2, 4, TA, TB, SC>(tid, q, LD, A, B, C, sc);
-        else wave_mm_blk<4, 4, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+        if (q <= 16) wave_mm_mfma<1, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+        else wave_mm_mfma<2, TA, TB, SC>(tid, q, LD, A, B, C, sc);
     } else {
         lds_mm<T, TA, TB, SC>(q, LD, A, B, C, sc);
     }
