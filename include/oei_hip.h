@@ -101,7 +101,10 @@ int oei_solution_derivative_batched(int B, int k_, int K, const double* M, const
 int oei_value_grad_batched(oei_model* m, int B, int q, const double* X,
                            double* value, double* grad, int* status, int* flags, void* stream);
 
-/* acquisition_hessian (oei.py:41-64, 105-135): X device [B,q,d] -> H device [B,q*d,q*d]. */
+/* acquisition_hessian (oei.py:41-64, 105-135): X device [B,q,d] -> H device [B,q*d,q*d].
+ * The per-candidate tables live in LDS: every q <= 32 is served for d up to about 12 (q = 20) or
+ * 7 (q = 32); above 32 only shapes with about (9 + d) q^2 doubles <= 160 KiB (q <= 36 at d = 6).
+ * Larger shapes return OEI_ERR_ARG with the byte count in oei_last_error(). */
 int oei_hessian_batched(oei_model* m, int B, int q, const double* X,
                         double* H, int* status, void* stream);
 
