@@ -245,8 +245,9 @@ __device__ __forceinline__ void zmat_mfma(const SdpWork w, int npad, size_t astr
 // and vc [CH] overlaid on everything behind w.H, which is idle while rows are staged), then
 // mu [q+2] and xq [q*d].  `full`: six-matrix layout (sensitivity kernels), else three.
 __host__ __device__ inline size_t acq_stage_doubles(int q) { return (size_t)q * (CH + 1) + CH; }
-__host__ __device__ inline size_t acq_lds_doubles(int q, int d, bool full) {
-    return sdp_region_doubles(q, acq_stage_doubles(q), full) + (size_t)(q + 2) + (size_t)q * d;
+// `staged`: the 256-thread kernels stage A rows; the one-wave kernels read them through the MFMAs.
+__host__ __device__ inline size_t acq_lds_doubles(int q, int d, bool staged) {
+    return sdp_region_doubles(q, staged ? acq_stage_doubles(q) : 0, false) + (size_t)(q + 2) + (size_t)q * d;
 }
 
 // ---- omega (oei.py:79-96) ------------------------------------------------------------------------
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q, false);
-    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q), false);
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, Q == 0 ? acq_stage_doubles(q) : 0, false);
     lds_f64* xq = mu + q + 2;
     lds_f64* Ac = w.S;
     lds_f64* vc = Ac + q * (CH + 1);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q, false);
-    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, acq_stage_doubles(q), false);
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, Q == 0 ? acq_stage_doubles(q) : 0, false);
     lds_f64* xq = mu + q + 2;
     lds_f64* Ac = w.S;
     lds_f64* vc = Ac + q * (CH + 1);
@@ -592,7 +593,7 @@ int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const d
         return OEI_ERR_ARG;
     }
 #define LAUNCH_STAGE2(T_, Q_) do { \
-        const size_t lds2 = acq_lds_doubles(q, m->d, false) * sizeof(double); \
+        const size_t lds2 = acq_lds_doubles(q, m->d, (Q_) == 0) * sizeof(double); \
         if ((rc = set_lds(k_stage2<T_, Q_>, lds2))) return rc; \
         hipLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z); } while (0)
     SDP_DISPATCH_Q(q, LAUNCH_STAGE2);
@@ -627,7 +628,7 @@ extern "C" int oei_omega_batched(oei_model* m, int B, int q, const double* X, do
         if ((rc = set_lds(k_omega<64, 32>, lds))) return rc;
         hipLaunchKernelGGL((k_omega<64, 32>), dim3(B), dim3(64), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
     } else {
-        const size_t lds = acq_lds_doubles(q, m->d, false) * sizeof(double);
+        const size_t lds = acq_lds_doubles(q, m->d, true) * sizeof(double);
         if ((rc = set_lds(k_omega<256, 0>, lds))) return rc;
         hipLaunchKernelGGL((k_omega<256, 0>), dim3(B), dim3(256), lds, st, m->kp, m->noise, m->n, m->npad, q, X, m->ws1, m->v, omega);
     }

@@ -85,18 +85,17 @@ struct SdpWork {
     lds_f64 *H, *S, *X;                   // q x LD matrices, both layouts
     lds_f64 *V, *R, *Kt;                  // full layout only (sensitivity kernels)
     lds_f64 *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci, *ip, *wp;   // vectors
-    lds_f64 *rc, *rs, *rt;                // 1/diag(Lc) | 1/s
-    lds_i32 *ri, *rj;
+    lds_f64 *rc, *rs;                     // 1/diag(Lc) | 1/s
     lds_f64 *scal;                        // [8] scalars
 };
-#define SDP_NVEC 16
+#define SDP_NVEC 15
 
 __host__ __device__ inline int sdp_ld(int q) { return q | 1; }
 __host__ __device__ inline int sdp_vlen(int q) { return (q + 3) & ~1; }   // even, >= q + 2
 
 __host__ __device__ inline size_t sdp_work_doubles(int q, bool full) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
-    return (size_t)(full ? 6 : 3) * q * LD + (size_t)SDP_NVEC * VL + VL /* ri,rj as ints */ + 8;
+    return (size_t)(full ? 6 : 3) * q * LD + (size_t)SDP_NVEC * VL + 8;
 }
 
 // Callers may use everything behind w.H (starting at w.S) as a staging buffer of `stage` doubles
@@ -116,8 +115,7 @@ __device__ inline void sdp_carve(SdpWork& w, double* base, int q, bool full) {
     w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
     w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
     w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;  w.ip = ptr; ptr += VL;
-    w.wp = ptr; ptr += VL; w.rc = ptr; ptr += VL;  w.rs = ptr; ptr += VL;  w.rt = ptr; ptr += VL;
-    w.ri = (lds_i32*)ptr; w.rj = w.ri + VL; ptr += VL;
+    w.wp = ptr; ptr += VL; w.rc = ptr; ptr += VL;  w.rs = ptr; ptr += VL;
     w.scal = ptr;
 }
 
