@@ -48,8 +48,10 @@ def select_best(rec, group=None):
     values = torch.where(torch.isnan(values), torch.full_like(values, float('inf')), values)
     vmin = values.min()
     cand = torch.where(values == vmin, indices, torch.full_like(indices, torch.iinfo(torch.int64).max))
-    win = int(torch.argmin(cand))
-    return allrec[win, 0], indices[win], allrec[win, 2:]
+    # the winner is picked on the device: no host synchronisation inside a step
+    win = torch.argmin(cand).reshape(1)
+    row = allrec.index_select(0, win).reshape(-1)
+    return row[0], indices.index_select(0, win).reshape(()), row[2:]
 
 
 def evaluate_and_select(gp, X_local, index_base=0, group=None):
