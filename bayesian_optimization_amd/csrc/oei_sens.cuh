@@ -154,7 +154,6 @@ __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_
 #pragma unroll
         for (int J = 0; J < NT; ++J) acc[I][J] = (sens_double4){0.0, 0.0, 0.0, 0.0};
     const int ks = (q + 3) >> 2;
-#pragma unroll 2
     for (int s = 0; s < ks; ++s) {
         const int k = 4 * s + kg;
         const bool kin = k < q;
