@@ -56,6 +56,18 @@ def test_value_grad_size_classes(cuda, q):
     _check_batch(om, dm, Xs)
 
 
+@pytest.mark.parametrize('q,d,n', [(1, 1, 5), (1, 6, 20), (2, 11, 30), (3, 12, 40), (5, 7, 65),
+                                   (15, 8, 129), (16, 2, 64), (31, 9, 100), (32, 5, 200),
+                                   (33, 11, 70), (64, 3, 90)])
+def test_value_grad_odd_shapes(cuda, q, d, n):
+    """Corners of the tiled kernels: q of one point, q at and around the 16-row MFMA tiles, d on
+    both sides of the limits of the fused GEMM + gradient contraction (d + 1 <= 8, <= 12, above),
+    training sizes below one K step, at a tile edge and one past it."""
+    om, dm = _mk(n, d=d, lengthscale=0.5 + 0.05 * d)
+    Xs = np.random.RandomState(100 + q + d).uniform(-.5, .5, (3, q, d))
+    _check_batch(om, dm, Xs, cert_tol=1e-7)
+
+
 def test_value_grad_cfg3_shape(cuda):
     """The largest configuration of the benchmark table: n = 1000, q = 50, d = 10 (wide path,
     generic-dimension kernels)."""
