@@ -98,6 +98,21 @@ def test_other_dimensions_value_grad_hessian(cuda, n, d, kind, fm, ls):
         assert np.abs(H[b] - Href).max() <= 1e-6 * scale                   # task bar: 1e-3
 
 
+@pytest.mark.parametrize('q,d,n', [(1, 6, 20), (16, 3, 40), (17, 4, 30)])
+def test_hessian_odd_shapes(cuda, q, d, n):
+    """acquisition_hessian at one point, and at both sides of the 16-row tile of the per-wave
+    matrix-pipe products."""
+    om, dm = _mk(n, d=d, lengthscale=0.6)
+    oracle = ooei.OEIOracle(om)
+    Xs = np.random.RandomState(7 + q).uniform(-.5, .5, (2, q, d))
+    H, status = dm.hessian(Xs)
+    H = H.cpu().numpy()
+    assert (status.cpu().numpy() == 0).all()
+    for b in range(2):
+        Href = oracle.acquisition_hessian(Xs[b].ravel())
+        assert np.abs(H[b] - Href).max() <= 1e-6 * np.abs(Href).max()      # task bar: 1e-3
+
+
 def test_hessian_lds_path(cuda):
     """acquisition_hessian for q > 32 (256-thread kernels) against the oracle."""
     om, dm = _mk(50)
