@@ -57,6 +57,9 @@
 #define SDP_JACOBI_FINAL_LOOSE 1e-5
 #define SDP_EVAL_WARM 1
 #define SDP_EVAL_LOOSE 2
+// the very first evaluation feeds a step of several per cent: it may stop a sweep earlier
+#define SDP_EVAL_FIRST 4
+#define SDP_JACOBI_FINAL_FIRST 1e-3
 
 // Inside one scheduling region: issue the LDS reads (up to nr) back to back, then the arithmetic,
 // and close the region.  Without this the register-pressure heuristic of the scheduler tends to
@@ -374,7 +377,7 @@ __device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps,
     {
         const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
         const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
-        const double fin = loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
+        const double fin = (mode & SDP_EVAL_FIRST) ? SDP_JACOBI_FINAL_FIRST : loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
         sweeps += sdp_jacobi_cols<T>(Gc, q, LD, tol * tol, fin * fin);
     }
     SDP_TOC(1, t_jac);
@@ -654,7 +657,7 @@ __device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* p
     {
         const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
         const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
-        const double fin = loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
+        const double fin = (mode & SDP_EVAL_FIRST) ? SDP_JACOBI_FINAL_FIRST : loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
         sweeps += sdp_jacobi_split<Q, RS>(gs, tol * tol, fin * fin);
     }
     SDP_TOC(1, t_jac);
@@ -1226,7 +1229,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
     for (;;) {
         // evaluations that only steer the iteration run with the loose Jacobi tolerance; the one
         // after a step below the stopping tolerance is the final state and runs tight
-        const int mode = first ? SDP_EVAL_LOOSE
+        const int mode = first ? (SDP_EVAL_LOOSE | SDP_EVAL_FIRST)
                                : (SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
         const double gv = sdp_eval_x<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
         if (first) {
