@@ -272,13 +272,15 @@ __device__ int sdp_jacobi_cols(lds_f64* Gc, int q, int LD, double tol2, double f
                 const double g2 = ga * ga, aa = al * be;
                 const bool rot = active && (g2 > tol2 * aa);
                 if (rot) {
-                    // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = beta - alpha
+                    // with d = beta - alpha, h = sqrt(d^2 + 4 gamma^2):  c^2 = (h + |d|) / (2 h),
+                    // s = sign(d) gamma / (h c)
                     const double d = be - al;
-                    const double x = fma(d, d, 4.0 * g2);
-                    const double h = x * sdp_rsq(x);
-                    double t = 2.0 * ga * sdp_rcp(fabs(d) + h);
-                    if (d < 0.0) t = -t;
-                    const double c = sdp_rsq(fma(t, t, 1.0)), sg = t * c;
+                    const double hinv = sdp_rsq(fma(d, d, 4.0 * g2));
+                    const double v = fma(0.5 * fabs(d), hinv, 0.5);
+                    const double rv = sdp_rsq(v);
+                    const double c = v * rv;
+                    double sg = ga * hinv * rv;
+                    if (d < 0.0) sg = -sg;
                     rotated |= (g2 > fin2 * aa) ? 1 : 0;
 #pragma unroll
                     for (int m = 0; m < MR; ++m) {
@@ -550,16 +552,18 @@ __device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
             const double g2 = gamma * gamma, aa = alpha * beta;
             const bool rot = g2 > tol2 * aa;
             if (rot) {
-                // t = sign(d) 2 gamma / (|d| + sqrt(d^2 + 4 gamma^2)),  d = alpha_j - alpha_i  (i < j)
+                // small-angle rotation that annihilates gamma: with d = alpha_j - alpha_i (i < j) and
+                // h = sqrt(d^2 + 4 gamma^2):  c^2 = (h + |d|) / (2 h),  s = sign(d) gamma / (h c),
+                // t = s / c.  Two reciprocal square roots, no division.
                 const double d = low ? beta - alpha : alpha - beta;
-                const double x = fma(d, d, 4.0 * g2);
-                const double h = x * sdp_rsq(x);
-                double t = 2.0 * gamma * sdp_rcp(fabs(d) + h);
-                if (d < 0.0) t = -t;
-                c = sdp_rsq(fma(t, t, 1.0));
-                const double ts = low ? -t : t;
-                sg = ts * c;                     // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
-                alpha = fma(ts, gamma, alpha);
+                const double hinv = sdp_rsq(fma(d, d, 4.0 * g2));
+                const double v = fma(0.5 * fabs(d), hinv, 0.5);
+                const double rv = sdp_rsq(v);                    // 1 / c
+                c = v * rv;
+                double sn = gamma * hinv * rv;
+                if (d < 0.0) sn = -sn;
+                sg = low ? -sn : sn;             // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
+                alpha = fma(sg * rv, gamma, alpha);
             }
             rotated |= rot && (g2 > fin2 * aa);
 #pragma unroll
