@@ -533,6 +533,7 @@ __device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
         // round-robin pairing of the columns: column c < Q-1 meets (2r - c) mod (Q-1), the fixed
         // point of that map meets column Q-1; `base` follows (2r - c) mod (Q-1) incrementally
         int base = (col < Q - 1) ? ((Q - 1 - col) % (Q - 1)) : 0;
+#pragma unroll 4
         for (int r = 0; r < Q - 1; ++r) {
             int pc = r;                                // partner of column Q-1
             if (col < Q - 1) pc = (base == col) ? Q - 1 : base;
