@@ -519,7 +519,7 @@ __device__ __forceinline__ double sdp_col_sum(double v, int col) {
 
 template <int Q, int RS>
 __device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
-    constexpr int P = 64 / Q;
+    constexpr int P = 64 / Q, UNR = Q <= 20 ? 4 : 1;
     const int lane = threadIdx.x & 63;
     const int col = lane % Q, part = lane / Q;
     const int poff = (part < P) ? part * Q : 0;       // left-over lanes hold zeros and read part 0
@@ -533,7 +533,10 @@ __device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
         // round-robin pairing of the columns: column c < Q-1 meets (2r - c) mod (Q-1), the fixed
         // point of that map meets column Q-1; `base` follows (2r - c) mod (Q-1) incrementally
         int base = (col < Q - 1) ? ((Q - 1 - col) % (Q - 1)) : 0;
-#pragma unroll 4
+        // unrolled by four in the small instances: the loop-carried column pieces then stay in
+        // place instead of being copied back at the end of every round (a tenth of the
+        // instructions of a round); the Q = 32 instance has no registers to spare for it
+#pragma unroll UNR
         for (int r = 0; r < Q - 1; ++r) {
             int pc = r;                                // partner of column Q-1
             if (col < Q - 1) pc = (base == col) ? Q - 1 : base;
