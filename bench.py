@@ -7,19 +7,31 @@ One step = one pass of the hot path over one batch of synthetic candidate batche
 in HBM: value + gradient of B candidates (q=20, d=6) under the n=310 hart6 GP, the local arg-min
 and, for N > 1, the all-gather of the (value, index, X) record that picks the best start.  Work per
 GPU is fixed (weak scaling).  Rank 0 prints ONE JSON line.
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process only launches: it starts N
+ranks of itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1),
+relays rank 0's JSON line and exits with the worst exit code.  It does so before anything touches
+the GPU.  Under an external launcher (torch.distributed.run) WORLD_SIZE is set and the process is a
+rank.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# cfg 2 (one GPU): 4096 candidate batches, seed 1.  cfg 4 (eight GPUs): 65 536 = 8192 per GPU, seed 3;
+# every multi-GPU run uses that per-GPU size so that work per GPU is the same for N = 2, 4, 8.
+BATCH_SINGLE, SEED_SINGLE = 4096, 1
+BATCH_MULTI, SEED_MULTI = 8192, 3
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = fp64 matrix peak (datasheet)
 
@@ -50,26 +62,46 @@ def flops_model(q, n, npad, newton_iters, sweeps):
     return moments + zmat + factor + evals * per_eval + sweeps * per_sweep + newton_iters * per_dir
 
 
-def cpu_baseline(model, X_sample, seconds_hint=20.0):
-    """The CPU restatement of the reference algorithm (oracle, first-order solve at eps=1e-5,
-    sdp.py:51) timed on the host, one candidate at a time, single thread."""
-    from oracle import oei as ooei
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:
-        ctx = None
-    orc = ooei.OEIOracle(model)
-    done, t0 = 0, time.time()
-    for b in range(X_sample.shape[0]):
-        orc.acquisition(X_sample[b], first_order=True)
-        done += 1
-        if time.time() - t0 > seconds_hint:
-            break
-    dt = time.time() - t0
-    if ctx is not None:
-        ctx.restore_original_limits() if hasattr(ctx, 'restore_original_limits') else None
-    return done / dt, done, dt
+def candidate_block(total, q, d, seed, lo, hi, chunk=4096):
+    """Rows [lo, hi) of the global candidate array RandomState(seed).uniform(-.5, .5, (total, q, d)),
+    drawn chunk by chunk so that a rank never holds more than its block plus one chunk."""
+    rs = np.random.RandomState(seed)
+    out = np.empty((hi - lo, q, d))
+    for c0 in range(0, min(total, hi), chunk):
+        c1 = min(total, c0 + chunk)
+        blk = rs.uniform(-0.5, 0.5, (c1 - c0, q, d))
+        a, b = max(lo, c0), min(hi, c1)
+        if a < b:
+            out[a - lo:b - lo] = blk[a - c0:b - c0]
+    return out
+
+
+# ---- launcher ------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks, argv):
+    """Start `n_ranks` copies of this script, one per GPU, and relay rank 0's output.  The parent
+    never initialises the GPU (it imports neither torch nor the package)."""
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout.read().decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    return bad[0] if bad else 0
 
 
 def main():
@@ -77,141 +109,187 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=4096, help='candidate batches per GPU')
+    ap.add_argument('--batch', type=int, default=0,
+                    help='candidate batches per GPU (default: %d on one GPU, %d per GPU on several)'
+                         % (BATCH_SINGLE, BATCH_MULTI))
+    ap.add_argument('--seed', type=int, default=-1, help='candidate seed (default: 1 on one GPU, 3 on several)')
     ap.add_argument('--q', type=int, default=20)
     ap.add_argument('--n', type=int, default=310)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=24.0, help='CPU-baseline budget, all legs together')
     ap.add_argument('--no-hessian', action='store_true', help='skip the Hessian throughput leg (profile runs: keeps the kernel statistics to the timed path)')
-    ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' only for rehearsing N > 1 on one GPU")
+    ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' only for rehearsing N > 1 on one GPU or on the CPU")
     ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses GPU 0')
+    ap.add_argument('--rehearse-cpu', action='store_true',
+                    help='rehearsal of the launcher, the sharding and the best-start exchange without a GPU: '
+                         'the evaluation is replaced by a closed-form stand-in; the printed rate means nothing')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.one_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    cpu_only = args.rehearse_cpu
+    if cpu_only:
+        args.backend = 'gloo'
+        dev = torch.device('cpu')
+    else:
+        if args.one_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)            # before the package import: its context goes here
+        dev = torch.device('cuda', local_rank)
     if world > 1:
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        world = dist.get_world_size()                # what the process group saw, not the flag
+    red_dev = dev if args.backend == 'nccl' else torch.device('cpu')
 
-    from bayesian_optimization_amd import DeviceGP, sdp_batched, multistart
+    from bayesian_optimization_amd import multistart
     from oracle import hart6, gp as ogp
 
-    q, n, B = args.q, args.n, args.batch
-    d = 6
-    model = hart6.make_model(n)                         # CPU copy: data + hyper-parameters only
-    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, model.kernel.variance,
-                  model.kernel.lengthscales, model.noise, floor_mode=model.kernel.floor_mode)
+    q, n, d = args.q, args.n, 6
+    B = args.batch or (BATCH_SINGLE if world == 1 else BATCH_MULTI)
+    seed = args.seed if args.seed >= 0 else (SEED_SINGLE if world == 1 else SEED_MULTI)
     total = B * world
     lo, hi = multistart.shard_bounds(total, world, rank)
-    # candidates: seed 1 stream, each rank takes its contiguous block of the global batch
-    rs = np.random.RandomState(1)
-    X_all = rs.uniform(-0.5, 0.5, (total, q, d)) if total <= 65536 else None
-    X_local = torch.as_tensor(X_all[lo:hi], dtype=torch.float64, device=dev).contiguous()
-    del X_all
+    X_local = torch.as_tensor(candidate_block(total, q, d, seed, lo, hi), dtype=torch.float64,
+                              device=dev).contiguous()
 
-    def step():
-        return multistart.evaluate_and_select(gp, X_local, index_base=lo)
+    if cpu_only:
+        gp = None
+
+        def step():
+            value = torch.sin(3.0 * X_local).sum(dim=(1, 2)) + X_local[:, 0, 0] ** 2
+            li = torch.argmin(value).reshape(1)
+            rec = multistart.make_record(value[li], li + lo, X_local.reshape(hi - lo, -1)[li])
+            bv, bi, bx = multistart.select_best(rec)
+            return value, None, torch.zeros(hi - lo, dtype=torch.int32), (bv, bi, bx.reshape(q, d))
+
+        def sync():
+            pass
+    else:
+        from bayesian_optimization_amd import DeviceGP, sdp_batched
+        model = hart6.make_model(n)                     # CPU copy: data + hyper-parameters only
+        gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, model.kernel.variance,
+                      model.kernel.lengthscales, model.noise, floor_mode=model.kernel.floor_mode)
+
+        def step():
+            return multistart.evaluate_and_select(gp, X_local, index_base=lo)
+
+        sync = torch.cuda.synchronize
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     value, grad, status, best = out
     n_bad = int((status != 0).sum().item())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nb = torch.tensor([n_bad], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(nb)
+        n_bad = int(nb.item())
 
     result = None
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         evals_per_s = total * args.steps / dt
-        # ---- roofline of the dominant kernel, measured live with HIP events on its stream ----
-        gp.set_profiling(True)
-        stage = np.zeros(5)
-        reps = 5
-        for _ in range(reps):
-            gp.value_grad(X_local, want_flags=False)
-            stage += np.array(gp.stage_times_ms())
-        stage /= reps
-        gp.set_profiling(False)
-        names = ['gram', 'gemm_cross', 'moments_sdp', 'gemm_back', 'gradient']
-        omg = gp.omega(X_local)
-        _, _, _, st2, iters = sdp_batched(omg, gp.fmin, want_Y=False)
-        iters = iters.cpu().numpy()
-        newton = (iters & 0xffff).astype(np.float64)
-        sweeps = (iters >> 16).astype(np.float64)
-        fl = sum(flops_model(q, n, gp.n + (-gp.n) % 64, a, b) for a, b in zip(newton, sweeps))
-        dom = int(np.argmax(stage))
-        sdp_ms = stage[2]
-        achieved = fl / (sdp_ms * 1e-3) / 1e12
-        traffic = None
-        prof_json = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(prof_json):
-            try:
-                traffic = json.load(open(prof_json)).get('moments_sdp_hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        roofline = {'bound': 'mfma', 'kernel': 'k_stage2 (posterior moments + SDP solve)',
-                    'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic,
-                    'launch_ms': sdp_ms, 'flops_per_launch': fl,
-                    'stage_ms': dict(zip(names, [float(x) for x in stage])),
-                    'dominant_stage': names[dom],
-                    'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
-        # Hessian throughput of the same model and candidates (second half of the metric), outside
-        # the timed region: a few calls on a slice of this rank's candidates
-        hessian = None
-        if not args.no_hessian:
-            hb = min(B, 2048)
-            gp.hessian(X_local[:hb])
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            for _ in range(3):
-                _, hst = gp.hessian(X_local[:hb])
-            torch.cuda.synchronize()
-            th = (time.perf_counter() - th) / 3
-            hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
-                       'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item())}
-        cpu = None
-        if not args.no_cpu_baseline:
-            v, done, secs = cpu_baseline(model, X_local[:24].cpu().numpy())
-            cpu = {'value': v, 'unit': 'evals/s', 'cores': 1, 'kind': 'port',
-                   'sample': '%d candidate batches (q=%d, n=%d) of the same workload, one at a time, '
-                             'numpy restatement of the reference path with the first-order SDP solve '
-                             'at eps=1e-5; %.1f s' % (done, q, n, secs)}
+        roofline = hessian = cpu = None
+        if not cpu_only:
+            # ---- roofline of the dominant kernel, measured live with HIP events on its stream ----
+            gp.set_profiling(True)
+            stage = np.zeros(5)
+            reps = 5
+            for _ in range(reps):
+                gp.value_grad(X_local, want_flags=False)
+                stage += np.array(gp.stage_times_ms())
+            stage /= reps
+            gp.set_profiling(False)
+            names = ['gram', 'gemm_cross', 'moments_sdp', 'gemm_back', 'gradient']
+            omg = gp.omega(X_local)
+            _, _, _, st2, iters = sdp_batched(omg, gp.fmin, want_Y=False)
+            iters = iters.cpu().numpy()
+            newton = (iters & 0xffff).astype(np.float64)
+            sweeps = (iters >> 16).astype(np.float64)
+            fl = sum(flops_model(q, n, gp.n + (-gp.n) % 64, a, b) for a, b in zip(newton, sweeps))
+            dom = int(np.argmax(stage))
+            sdp_ms = stage[2]
+            achieved = fl / (sdp_ms * 1e-3) / 1e12
+            traffic = None
+            prof_json = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+            if os.path.exists(prof_json):
+                try:
+                    traffic = json.load(open(prof_json)).get('moments_sdp_hbm_bytes_per_launch')
+                except Exception:
+                    traffic = None
+            roofline = {'bound': 'fp64 VALU issue', 'kernel': 'k_stage2 (posterior moments + SDP solve)',
+                        'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic,
+                        'peak_note': 'fp64 vector peak = fp64 matrix peak on MI355X; two thirds of the '
+                                     "kernel's flops and nearly all of its time are vector arithmetic",
+                        'launch_ms': sdp_ms, 'flops_per_launch': fl,
+                        'stage_ms': dict(zip(names, [float(x) for x in stage])),
+                        'dominant_stage': names[dom],
+                        'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
+            # Hessian throughput of the same model and candidates (second half of the metric), outside
+            # the timed region: a few calls on a slice of this rank's candidates
+            if not args.no_hessian:
+                hb = min(B, 2048)
+                gp.hessian(X_local[:hb])
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                for _ in range(3):
+                    _, hst = gp.hessian(X_local[:hb])
+                torch.cuda.synchronize()
+                th = (time.perf_counter() - th) / 3
+                hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
+                           'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item())}
+            if not args.no_cpu_baseline and world == 1:
+                # the CPU restatement of the reference path (oracle) timed on this box's host
+                # cores, on a bounded sample of the benchmark's own candidates
+                from oracle import cpu_bench
+                cpu = cpu_bench.run_all(n, q, X_local[:256].cpu().numpy(), args.cpu_seconds)
+        bx = best[2].detach().cpu().contiguous().numpy()
         result = {
             'metric': 'OEI value+grad evals/sec (q=%d, n=%d)' % (q, n),
             'value': evals_per_s, 'unit': 'evals/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'cfg2: hart6 GP n=%d, q=%d, d=%d, %d multistart candidate batches '
-                                   'per GPU, value+gradient + best-start selection' % (n, q, d, B),
+            'config': {'workload': '%s: hart6 GP n=%d, q=%d, d=%d, %d multistart candidate batches '
+                                   'per GPU (seed %d), value+gradient + best-start selection'
+                                   % ('cfg2' if world == 1 else 'cfg4 recipe', n, q, d, B, seed),
                        'candidates_total': total, 'candidates_per_gpu': B,
-                       'parallelism': 'candidates sharded over %d GPU(s), one all-gather of a %d-byte record'
-                                      % (world, 8 * (2 + q * d))},
+                       'parallelism': 'candidates sharded over %d rank(s) (%s), one GPU each, '
+                                      'one all-gather of a %d-byte record'
+                                      % (world, ('world size seen by ' + args.backend) if world > 1 else 'no process group',
+                                         8 * (2 + q * d))},
             'unconverged': n_bad,
-            'best': {'value': float(best[0].item()), 'index': int(best[1].item())},
+            'best': {'value': float(best[0].item()), 'index': int(best[1].item()),
+                     'x_sha1': hashlib.sha1(bx.tobytes()).hexdigest()},
             'hessian': hessian, 'roofline': roofline, 'cpu_baseline': cpu,
         }
-        print(json.dumps(result))
+        if cpu_only:
+            result['data'] = 'synthetic; CPU rehearsal of the launcher (stand-in evaluation, rate meaningless)'
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -153,3 +153,38 @@ def test_select_best_single_process_handles_nan():
     rec = multistart.make_record(torch.tensor(float('nan')), torch.tensor(3), torch.zeros(4))
     v, i, x = multistart.select_best(rec)
     assert int(i) == 3
+
+
+def _run_bench(*flags):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(flags), env=env,
+                         stdout=subprocess.PIPE, timeout=300, check=True).stdout.decode()
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_launcher_starts_n_ranks():
+    """`bench.py --gpus 2` must itself start two ranks (rehearsed on the CPU: gloo, stand-in
+    evaluation), shard the same global candidate array and pick the start one rank would pick."""
+    two = _run_bench('--gpus', '2', '--rehearse-cpu', '--batch', '96', '--seed', '3', '--steps', '2', '--warmup', '1')
+    one = _run_bench('--gpus', '1', '--rehearse-cpu', '--batch', '192', '--seed', '3', '--steps', '2', '--warmup', '1')
+    assert two['n_gpus'] == 2 and one['n_gpus'] == 1
+    assert two['config']['candidates_total'] == one['config']['candidates_total'] == 192
+    assert two['best']['index'] == one['best']['index']
+    assert two['best']['x_sha1'] == one['best']['x_sha1']          # bit-identical best X
+    assert two['best']['value'] == one['best']['value']
+    assert '2 rank(s)' in two['config']['parallelism']
+
+
+def test_bench_candidate_blocks_tile_the_global_array():
+    import bench
+    full = bench.candidate_block(300, 4, 3, 5, 0, 300, chunk=64)
+    assert np.array_equal(full, np.random.RandomState(5).uniform(-.5, .5, (300, 4, 3)))
+    for lo, hi in [(0, 100), (100, 200), (37, 38), (250, 300)]:
+        assert np.array_equal(bench.candidate_block(300, 4, 3, 5, lo, hi, chunk=64), full[lo:hi])
