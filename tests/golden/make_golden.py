@@ -43,7 +43,13 @@ def ref_sdp_inputs():
     return out
 
 
-def main():
+def main(only=None):
+    if only is None:
+        make_sdp_fixture()
+    make_oei_fixtures(only)
+
+
+def make_sdp_fixture():
     inst = ref_sdp_inputs()
     om = np.stack([o for o, _ in inst])
     fm = np.array([f for _, f in inst])
@@ -56,7 +62,15 @@ def main():
                         value=np.array(vals), M=np.stack(Ms), Y=np.stack(Ys))
     print('sdp_reference_inputs: values', np.round(vals, 6))
 
-    for n, q, seed in [(10, 1, 101), (10, 3, 102), (25, 3, 103), (25, 8, 104), (310, 20, 105)]:
+
+
+def make_oei_fixtures(only=None):
+    # (10, 20): the single-evaluation configuration of the benchmark table (q = 20 on the 10-point
+    # initial design)
+    for n, q, seed in [(10, 1, 101), (10, 3, 102), (25, 3, 103), (25, 8, 104), (310, 20, 105),
+                       (10, 20, 106)]:
+        if only is not None and (n, q) not in only:
+            continue
         model = hart6.make_model(n)
         orc = ooei.OEIOracle(model)
         X = np.random.RandomState(seed).uniform(-0.5, 0.5, (q, 6))
@@ -88,4 +102,6 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    # optional arguments "n,q" restrict the run to those fixtures
+    sel = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
+    main(sel or None)

@@ -151,3 +151,19 @@ def test_project_cases():
 def test_hart6_matches_published_minimum():
     xmin = np.array([0.20169, 0.150011, 0.476874, 0.275332, 0.311652, 0.6573])
     assert abs(hart6.hart6_unit(xmin)[0, 0] - hart6.HART6_FMIN) < 1e-4
+
+
+def test_objective_against_reference_run():
+    """hart6 / scale_function of the oracle and of the product driver against outputs of the
+    reference's own benchmark_functions.py (tests/golden/make_hart6_fixture.py ran it; the
+    fixture holds inputs and outputs only)."""
+    from bayesian_optimization_amd import benchmarks
+    g = np.load(os.path.join(GOLD, 'hart6_reference.npz'))
+    assert np.abs(hart6.hart6_unit(g['X_unit']) - g['f_unit']).max() < 1e-14
+    assert np.abs(hart6.hart6_scaled(g['X_scaled']) - g['f_scaled']).max() < 1e-14
+    prod = benchmarks.scale_function(benchmarks.hart6())
+    assert np.abs(benchmarks.hart6().f(g['X_unit']) - g['f_unit']).max() < 1e-14
+    assert np.abs(prod.f(g['X_scaled']) - g['f_scaled']).max() < 1e-14
+    assert np.abs(prod.restore(g['X_scaled']) - g['restored']).max() < 1e-15
+    assert np.abs(prod.scale(g['X_unit']) - g['rescaled']).max() < 1e-15
+    assert np.array_equal(prod.bounds, g['bounds']) and prod.fmin == float(g['fmin'])
