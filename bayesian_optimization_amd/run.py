@@ -4,7 +4,7 @@
         --initial_size=10 --iterations=15 --noise=1e-6
 
 writes `out/<function>_<algorithm>/<seed>.npz` (arrays X, Y), `arguments.pkl`, `fmin.txt`
-(run.py:26-71, 105-133) and logs to `log/<job>/` (bo.py:257-276).  Differences, all forced by what
+(run.py:26-71, 105-133) and logs to `log/<job>/<seed>/` (bo.py:257-276).  Differences, all forced by what
 is installed: `--nl_solver` defaults to `lockstep` (the reference's default, KNITRO, is proprietary;
 `bfgs` and `newton` are the other choices), the objective comes from `oracle/hart6.py`-equivalent
 formulas in `benchmarks.py`, the kernels are this package's descriptions instead of gpflow objects,
@@ -22,8 +22,9 @@ import numpy as np
 
 
 def setup_logging(job_name, seed):
-    """Three log files per run as bo.py:257-276 / logging.yaml: evaluations, model, optimiser."""
-    folder = os.path.join('log', job_name)
+    """Three log files per run, `log/<job>/<seed>/{evals,opt,model}.log`, bare messages, no
+    propagation: bo.py:257-276 with logging.yaml:15-42."""
+    folder = os.path.join('log', job_name, str(seed))
     os.makedirs(folder, exist_ok=True)
     for name in ('evals', 'model', 'opt'):
         logger = logging.getLogger(name)
@@ -31,7 +32,7 @@ def setup_logging(job_name, seed):
         logger.propagate = False
         for h in list(logger.handlers):
             logger.removeHandler(h)
-        handler = logging.FileHandler(os.path.join(folder, '%d_%s.log' % (seed, name)), mode='w')
+        handler = logging.FileHandler(os.path.join(folder, name + '.log'), mode='w')
         handler.setFormatter(logging.Formatter('%(message)s'))
         logger.addHandler(handler)
 

@@ -62,7 +62,7 @@ def test_driver_end_to_end(cuda, tmp_path, monkeypatch):
     with open(os.path.join('out', 'hart6_OEI', 'arguments.pkl'), 'rb') as fh:
         assert pickle.load(fh).seed == 7
     for name in ('evals', 'model', 'opt'):
-        assert os.path.getsize(os.path.join('log', 'hart6_OEI', '7_%s.log' % name)) > 0
+        assert os.path.getsize(os.path.join('log', 'hart6_OEI', '7', name + '.log')) > 0
     # same seed, same run
     run.main(args)
     assert np.array_equal(np.load(os.path.join('out', 'hart6_OEI', '7.npz'))['X'], X)
