@@ -636,61 +636,63 @@ extern "C" int oei_omega_batched(oei_model* m, int B, int q, const double* X, do
     return OEI_OK;
 }
 
-extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* X, double* value,
-                                      double* grad, int* status, int* flags, void* stream) {
-    int rc = check_model_call(m, B, q, X, "value_grad_batched");
-    if (rc) return rc;
-    if (B == 0) return OEI_OK;
-    if (!value || !grad || !status) { oei_set_error("value_grad_batched: null output"); return OEI_ERR_ARG; }
-    hipStream_t st = (hipStream_t)stream;
+// Per-candidate state behind the three row buffers: p [B q], M11 [B q q], partial gradient sums
+// [npad/64][B q][d+1].
+static inline size_t value_grad_aux_doubles(const oei_model* m, int B, int q) {
+    return (size_t)B * q + (size_t)B * q * q + (size_t)(m->npad / 64) * B * q * (m->d + 1);
+}
+
+// The five launches of the value+gradient path on caller-chosen scratch: ws0, ws1, ws2 hold
+// rows_pad x npad doubles each (Ks then Z | A | K1), aux holds value_grad_aux_doubles().  Nothing
+// in here allocates.
+static int value_grad_run(oei_model* m, int B, int q, const double* X, double* value, double* grad,
+                          int* status, int* flags, hipStream_t st, double* ws0, double* ws1,
+                          double* ws2, double* aux) {
+    int rc;
     const int d = m->d;
     const size_t rows = (size_t)B * q, rows_pad = round_up(rows, 64);
-    const size_t aux_bytes = ((size_t)B * q + (size_t)B * q * q + (size_t)(m->npad / 64) * B * q * (d + 1)) * sizeof(double);
     const bool prof = m->profile != 0;
-    rc = oei_ws_reserve(m, rows_pad, aux_bytes);
-    if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[0], st));
-    if ((rc = oei_ws2_reserve(m, rows_pad))) return rc;
     if (flags) OEI_HIP_CHECK(hipMemsetAsync(flags, 0, (size_t)B * sizeof(int), st));
-    rc = oei_launch_gram(m, X, rows, rows_pad, m->ws0, m->ws2, q, flags, st);   // ws0 = Ks, ws2 = K1
+    rc = oei_launch_gram(m, X, rows, rows_pad, ws0, ws2, q, flags, st);   // ws0 = Ks, ws2 = K1
     if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[1], st));
-    rc = oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows_pad, m->npad, 1, st);   // ws1 = A
+    rc = oei_launch_gemm_nt(ws0, m->Linv, ws1, rows_pad, m->npad, 1, st);   // ws1 = A
     if (rc) return rc;
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[2], st));
-    double* p_buf = m->aux;
-    double* M11_buf = m->aux + (size_t)B * q;
+    double* p_buf = aux;
+    double* M11_buf = aux + (size_t)B * q;
     const size_t ldsg = ((size_t)q * d + 2 * (size_t)q * q + q + (size_t)q * (CH + 1) + (size_t)CH * ((d + 1) | 1) + (size_t)q * (d + 1)) * sizeof(double);
     if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
         return OEI_ERR_ARG;
     }
-    rc = oei_launch_stage2(m, B, q, X, m->ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, m->ws0, st);
+    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, ws0, st);
     if (rc) return rc;
     if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
-        OEI_HIP_CHECK(hipMemsetAsync(m->ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
+        OEI_HIP_CHECK(hipMemsetAsync(ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[3], st));
     if (d + 1 <= OEI_GG_MAX_DP) {
         // W = Z L^-1 contracted with K1 and X inside the GEMM; a small per-candidate kernel finishes
         double* Gpart = M11_buf + (size_t)B * q * q;
-        rc = oei_launch_gemm_grad(m, m->ws0, m->ws2, p_buf, Gpart, rows, rows_pad, st);
+        rc = oei_launch_gemm_grad(m, ws0, ws2, p_buf, Gpart, rows, rows_pad, st);
         if (rc) return rc;
         if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
         const size_t ldsf = ((size_t)q * d + 2 * (size_t)q * q + (size_t)q * (d + 1)) * sizeof(double);
         if ((rc = set_lds(k_grad_fin, ldsf))) return rc;
         hipLaunchKernelGGL(k_grad_fin, dim3(B), dim3(64), ldsf, st, m->kp, q, rows, m->npad / 64, X, Gpart, M11_buf, grad, flags);
     } else {
-        rc = oei_launch_gemm_nt(m->ws0, m->LinvT, m->ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
+        rc = oei_launch_gemm_nt(ws0, m->LinvT, ws1, rows_pad, m->npad, 0, st);   // ws1 = W = Z L^-1
         if (rc) return rc;
         if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
         // four waves per candidate split its points four ways and overlap their memory latencies
         // (measured at q = 20: 0.29 ms with one wave, 0.19 ms with four, 0.26 ms with eight)
         if (q <= 4) {
             if ((rc = set_lds(k_grad<64>, ldsg))) return rc;
-            hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
+            hipLaunchKernelGGL(k_grad<64>, dim3(B), dim3(64), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, ws1, ws2, p_buf, M11_buf, grad, flags);
         } else {
             if ((rc = set_lds(k_grad<256>, ldsg))) return rc;
-            hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, m->ws1, m->ws2, p_buf, M11_buf, grad, flags);
+            hipLaunchKernelGGL(k_grad<256>, dim3(B), dim3(256), ldsg, st, m->kp, m->n, m->npad, q, m->X, m->alpha, X, ws1, ws2, p_buf, M11_buf, grad, flags);
         }
     }
     OEI_HIP_CHECK(hipGetLastError());
@@ -698,10 +700,76 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     return OEI_OK;
 }
 
+// Scratch of the entry point that allocates nothing: one array per GPU, in the code object's own
+// global memory.  In host code the array's name is only a stand-in: the device address comes from
+// hipGetSymbolAddress, once per device with that device current, and is what kernels, memsets and
+// copies get.  32 MiB: about 200 candidates at q = 20, n = 310.
+static __device__ __align__(256) double scratch[OEI_NOALLOC_SCRATCH_DOUBLES];
+#define OEI_MAX_DEVICES 64
+static double* scratch_ptr[OEI_MAX_DEVICES];          // per-device address of `scratch`
+
+// Looks up this device's copy of the scratch array (no allocation).  Called by oei_model_create
+// for the model's device and, if a device was never set up, by the entry point itself.
+int oei_noalloc_setup_device(int device) {
+    if (device < 0 || device >= OEI_MAX_DEVICES) { oei_set_error("noalloc: device %d out of range", device); return OEI_ERR_ARG; }
+    if (scratch_ptr[device]) return OEI_OK;
+    int cur = -1;
+    OEI_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != device) { oei_set_error("noalloc: device %d is not current (current: %d)", device, cur); return OEI_ERR_ARG; }
+    void* ptr = nullptr;
+    OEI_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) { oei_set_error("noalloc: no address for the scratch array on device %d", device); return OEI_ERR_HIP; }
+    scratch_ptr[device] = (double*)ptr;
+    return OEI_OK;
+}
+
+extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* X, double* value,
+                                      double* grad, int* status, int* flags, void* stream) {
+    int rc = check_model_call(m, B, q, X, "value_grad_batched");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    if (!value || !grad || !status) { oei_set_error("value_grad_batched: null output"); return OEI_ERR_ARG; }
+    const size_t rows_pad = round_up((size_t)B * q, 64);
+    if ((rc = oei_ws_reserve(m, rows_pad, value_grad_aux_doubles(m, B, q) * sizeof(double)))) return rc;
+    if ((rc = oei_ws2_reserve(m, rows_pad))) return rc;
+    return value_grad_run(m, B, q, X, value, grad, status, flags, (hipStream_t)stream, m->ws0, m->ws1, m->ws2, m->aux);
+}
+
+extern "C" int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const double* X, double* value,
+                                              double* grad, int* status, int* flags, void* stream) {
+    int rc = check_model_call(m, B, q, X, "value_grad_batched_noalloc");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    if (!value || !grad || !status) { oei_set_error("value_grad_batched_noalloc: null output"); return OEI_ERR_ARG; }
+    const size_t rows_pad = round_up((size_t)B * q, 64);
+    const size_t buf = rows_pad * (size_t)m->npad;                       // a multiple of 64 * 64 doubles
+    const size_t need = 3 * buf + round_up(value_grad_aux_doubles(m, B, q), 32);
+    if (need > (size_t)OEI_NOALLOC_SCRATCH_DOUBLES) {
+        oei_set_error("value_grad_batched_noalloc: B=%d q=%d n=%d needs %zu doubles of scratch, the fixed "
+                      "array holds %zu (use oei_value_grad_batched)", B, q, m->n, need, (size_t)OEI_NOALLOC_SCRATCH_DOUBLES);
+        return OEI_ERR_ARG;
+    }
+    if (m->device < 0 || m->device >= OEI_MAX_DEVICES) { oei_set_error("noalloc: device %d out of range", m->device); return OEI_ERR_ARG; }
+    if (!scratch_ptr[m->device] && (rc = oei_noalloc_setup_device(m->device))) return rc;
+    double* base = scratch_ptr[m->device];
+    return value_grad_run(m, B, q, X, value, grad, status, flags, (hipStream_t)stream,
+                          base, base + buf, base + 2 * buf, base + 3 * buf);
+}
+
 extern "C" int oei_set_profiling(oei_model* m, int on) {
     if (!m) { oei_set_error("set_profiling: null model"); return OEI_ERR_ARG; }
-    if (on && !m->ev[0])
-        for (int i = 0; i < 6; ++i) OEI_HIP_CHECK(hipEventCreate(&m->ev[i]));
+    if (on && !m->ev[0]) {
+        hipEvent_t tmp[6] = {};
+        for (int i = 0; i < 6; ++i) {
+            const hipError_t e = hipEventCreate(&tmp[i]);
+            if (e != hipSuccess) {           // all six or none
+                for (int j = 0; j < i; ++j) hipEventDestroy(tmp[j]);
+                oei_set_error("set_profiling: hipEventCreate failed: %s", hipGetErrorString(e));
+                return OEI_ERR_HIP;
+            }
+        }
+        for (int i = 0; i < 6; ++i) m->ev[i] = tmp[i];
+    }
     m->profile = on;
     m->ev_valid = 0;
     return OEI_OK;

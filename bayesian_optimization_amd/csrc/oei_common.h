@@ -108,6 +108,8 @@ int oei_ws_reserve(oei_model* m, size_t rows, size_t aux_bytes);
 int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
                     double* Ks, double* K1, int q, int* flags, hipStream_t st);
 int oei_ws2_reserve(oei_model* m, size_t rows);
+// Looks up the current device's copy of the fixed scratch array of oei_value_grad_batched_noalloc.
+int oei_noalloc_setup_device(int device);
 // Extended rows of the Hessian path: per candidate RP rows (value rows, derivative rows, y, zeros).
 int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int RP, double* out,
                         hipStream_t st);

@@ -265,7 +265,11 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
 
     oei_model* m = new oei_model();
     memset(m, 0, sizeof(*m));
-    OEI_HIP_CHECK(hipGetDevice(&m->device));
+    if (hipGetDevice(&m->device) != hipSuccess) { delete m; oei_set_error("model_create: hipGetDevice failed"); return OEI_ERR_HIP; }
+    if (m->device < 64) {       // set-up of the allocation-free entry point for this device
+        const int src = oei_noalloc_setup_device(m->device);
+        if (src != OEI_OK) { delete m; return src; }
+    }
     m->n = n; m->d = d; m->noise = noise;
     m->npad = ((n + OEI_NPAD - 1) / OEI_NPAD) * OEI_NPAD;
     m->kp.kind = kernel_kind; m->kp.floor_mode = floor_mode; m->kp.d = d; m->kp.variance = variance;
@@ -331,8 +335,11 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
 
 extern "C" int oei_model_destroy(oei_model* m) {
     if (!m) return OEI_OK;
-    hipSetDevice(m->device);
+    int cur = -1;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (!have || cur != m->device) hipSetDevice(m->device);
     model_free(m);
+    if (have && cur != m->device) hipSetDevice(cur);      // the caller's device stays current
     return OEI_OK;
 }
 

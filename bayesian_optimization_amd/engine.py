@@ -66,7 +66,7 @@ class DeviceGP:
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
-            lib.oei_model_destroy(self._h)
+            lib.oei_model_destroy(self._h)          # leaves the caller's current device as it was
             self._h = ctypes.c_void_p(0)
 
     def __del__(self):
@@ -126,18 +126,24 @@ class DeviceGP:
             check(lib.oei_omega_batched(self._h, B, q, _ptr(X), _ptr(om), _stream()), 'oei_omega_batched')
         return om
 
-    def value_grad(self, X, want_flags=True):
-        """[B,q,d] -> value [B], grad [B,q,d], status int32 [B], flags int32 [B]."""
+    def value_grad(self, X, want_flags=True, out=None, no_alloc=False):
+        """[B,q,d] -> value [B], grad [B,q,d], status int32 [B], flags int32 [B].
+        `out`: (value, grad, status, flags) tensors to write into instead of new ones.
+        `no_alloc`: use the entry point that works in the library's fixed scratch array (small
+        batches only); with `out` given, the call then allocates no device memory at all."""
         X = self._batch(X)
         B, q, d = X.shape
-        value = torch.empty(B, dtype=torch.float64, device=self.device)
-        grad = torch.empty((B, q, d), dtype=torch.float64, device=self.device)
-        status = torch.empty(B, dtype=torch.int32, device=self.device)
-        flags = torch.empty(B, dtype=torch.int32, device=self.device) if want_flags else None
+        if out is not None:
+            value, grad, status, flags = out
+        else:
+            value = torch.empty(B, dtype=torch.float64, device=self.device)
+            grad = torch.empty((B, q, d), dtype=torch.float64, device=self.device)
+            status = torch.empty(B, dtype=torch.int32, device=self.device)
+            flags = torch.empty(B, dtype=torch.int32, device=self.device) if want_flags else None
+        fn = lib.oei_value_grad_batched_noalloc if no_alloc else lib.oei_value_grad_batched
         with torch.cuda.device(self.device):
-            check(lib.oei_value_grad_batched(self._h, B, q, _ptr(X), _ptr(value), _ptr(grad),
-                                             _ptr(status), _ptr(flags), _stream()),
-                  'oei_value_grad_batched')
+            check(fn(self._h, B, q, _ptr(X), _ptr(value), _ptr(grad), _ptr(status), _ptr(flags), _stream()),
+                  'oei_value_grad_batched_noalloc' if no_alloc else 'oei_value_grad_batched')
         return value, grad, status, flags
 
     def hessian(self, X):

@@ -42,6 +42,7 @@ extern "C" {
 #define OEI_FLOOR_STOCK  2   /* r = sqrt(r2 + 1e-12)       tests/create_model.py:28 (stock Matern32) */
 
 #define OEI_MAX_Q   64       /* largest batch size q the kernels accept */
+#define OEI_NOALLOC_SCRATCH_DOUBLES (4u << 20)   /* fixed scratch of oei_value_grad_batched_noalloc: 32 MiB per GPU */
 #define OEI_MAX_DIM 32       /* largest input dimension d */
 
 typedef struct oei_model oei_model;   /* opaque GP model handle */
@@ -100,6 +101,18 @@ int oei_solution_derivative_batched(int B, int k_, int K, const double* M, const
  * X/l to two decimals); the host shim re-evaluates those candidates on the reduced point set. */
 int oei_value_grad_batched(oei_model* m, int B, int q, const double* X,
                            double* value, double* grad, int* status, int* flags, void* stream);
+
+/* The same evaluation for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Identical arguments and results (bitwise) to oei_value_grad_batched, but the intermediates
+ * (kernel rows, A = Ks L^-T, Z, per-candidate state) live in a fixed 32 MiB array that every GPU
+ * the library runs on holds until the process ends; the call performs no hipMalloc/hipFree.
+ * Limit: 3 * roundup(B*q, 64) * roundup(n, 64) + B*q*(1 + q + (d+1) * roundup(n,64)/64) doubles must
+ * fit in OEI_NOALLOC_SCRATCH_DOUBLES (about 200 candidates at q = 20, n = 310); larger calls
+ * return OEI_ERR_ARG with both numbers in oei_last_error().  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const double* X,
+                                   double* value, double* grad, int* status, int* flags, void* stream);
 
 /* acquisition_hessian (oei.py:41-64, 105-135): X device [B,q,d] -> H device [B,q*d,q*d].
  * The per-candidate tables live in LDS: every q <= 32 is served for d up to about 12 (q = 20) or
