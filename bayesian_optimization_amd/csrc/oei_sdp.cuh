@@ -55,6 +55,9 @@
 // evaluations that only steer the Newton iteration (every one but the last) stop earlier
 #define SDP_JACOBI_TOL_LOOSE 1e-11
 #define SDP_JACOBI_FINAL_LOOSE 1e-5
+#ifndef SDP_UNR_WIDE
+#define SDP_UNR_WIDE 1      // unroll factor of the Jacobi round loop in the Q = 32 instance
+#endif
 #define SDP_EVAL_WARM 1
 #define SDP_EVAL_LOOSE 2
 // the very first evaluation feeds a step of several per cent: it may stop a sweep earlier
@@ -519,7 +522,7 @@ __device__ __forceinline__ double sdp_col_sum(double v, int col) {
 
 template <int Q, int RS>
 __device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
-    constexpr int P = 64 / Q, UNR = Q <= 20 ? 4 : 1;
+    constexpr int P = 64 / Q, UNR = Q <= 20 ? 4 : SDP_UNR_WIDE;
     const int lane = threadIdx.x & 63;
     const int col = lane % Q, part = lane / Q;
     const int poff = (part < P) ? part * Q : 0;       // left-over lanes hold zeros and read part 0
@@ -1210,6 +1213,30 @@ __device__ __forceinline__ int sdp_newton_dir(const SdpWork w) {
 // ================================================================================================
 // The loop is written as a state machine so that the evaluation has a single (inlined) call site:
 // first the start point, then one or more trial points per Newton iteration.
+// Pieces as sdp_solve_impl uses them: inlined, except in the Q = 32 instance.  Inlined there, the
+// padded (q < 32) solver needs about 1000 scalar registers spilled into lanes of vector registers
+// and, at 256 vector registers, the compiler spills those carrier registers to scratch memory in
+// turn; code built that way returned wrong iterates for q = 21..31 (with the Jacobi round loop
+// unrolled: 61 Newton iterations, values off by 5e-3), and the same source built with
+// -mllvm -amdgpu-spill-sgpr-to-vgpr=false was correct, so the defect is in that spill path, not
+// in the arithmetic.  Out of line, every piece has a register allocation of its own and no
+// carrier register is spilled (tests/test_cpu_host.py checks the built code for that pattern).
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ int sdp_factor_s(const SdpWork w) {
+    if constexpr (Q == 32) return sdp_factor_call<T, Q, EXACT>(w);
+    else return sdp_factor_x<T, Q, EXACT>(w);
+}
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ double sdp_eval_s(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+    if constexpr (Q == 32) return sdp_eval_call<T, Q, EXACT>(w, pt, sweeps, mode);
+    else return sdp_eval_x<T, Q, EXACT>(w, pt, sweeps, mode);
+}
+template <int T, int Q, bool EXACT>
+__device__ __forceinline__ int sdp_newton_dir_s(const SdpWork w) {
+    if constexpr (Q == 32) return sdp_newton_dir_call<T, Q, EXACT>(w);
+    else return sdp_newton_dir_x<T, Q, EXACT>(w);
+}
+
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, int* iters_out) {
     const int tid = threadIdx.x;
@@ -1230,7 +1257,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
 #ifdef OEI_SDP_TIMING
     if (tid == 0) { for (int i = 0; i < 8; ++i) w.scal[i] = 0.0; }
 #endif
-    if (sdp_factor_x<T, Q, EXACT>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
+    if (sdp_factor_s<T, Q, EXACT>(w)) { *g_out = -INFINITY; *iters_out = 0; return 2; }
     double g = -INFINITY, t = 1.0, dec = 0.0, slack = 0.0, rel = 1.0;
     bool first = true, full = true, finish = false;
     int ls = 0;
@@ -1239,7 +1266,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         // after a step below the stopping tolerance is the final state and runs tight
         const int mode = first ? (SDP_EVAL_LOOSE | SDP_EVAL_FIRST)
                                : (SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
-        const double gv = sdp_eval_x<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
+        const double gv = sdp_eval_s<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
         if (first) {
             first = false;
             g = gv;
@@ -1261,7 +1288,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         }
         if (++it > SDP_MAX_NEWTON) break;
         SDP_TIC(t_dir);
-        const int dir_fail = sdp_newton_dir_x<T, Q, EXACT>(w);
+        const int dir_fail = sdp_newton_dir_s<T, Q, EXACT>(w);
         SDP_TOC(3, t_dir);
         if (dir_fail) { status = 2; break; }
         double ssum = 0.0, psum = 0.0;

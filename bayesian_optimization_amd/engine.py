@@ -16,7 +16,7 @@ KERNEL_RBF = 0
 KERNEL_MATERN32 = 1
 FLOOR_NONE, FLOOR_SAFE, FLOOR_STOCK = 0, 1, 2
 
-STATUS_TEXT = {0: 'Solved', 1: 'Iteration limit', 2: 'Numerical breakdown', 3: 'Eigen-iteration limit'}
+STATUS_TEXT = {0: 'Solved', 1: 'Iteration limit', 2: 'Numerical breakdown'}
 
 
 def _ptr(t):

@@ -17,9 +17,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
  *     stream-ordered; they return once the work is enqueued unless stated otherwise.
  *   - matrices are dense row-major.  k_ = q + 1.
- *   - per-candidate `status`: 0 = converged, 1 = iteration limit reached, 2 = numerical breakdown
- *     (Omega not positive definite, NaN), 3 = eigen-iteration limit.  Like the reference
- *     (sdp.py:53-56: warn and continue) a non-zero status never aborts the batch.
+ *   - per-candidate `status`: 0 = converged, 1 = Newton iteration limit reached (the result is the
+ *     last iterate), 2 = numerical breakdown (Omega not positive definite, NaN; outputs are NaN).
+ *     Like the reference (sdp.py:53-56: warn and continue) a non-zero status never aborts the
+ *     batch.  The eigen-iteration (Jacobi) has a cap of 30 sweeps per evaluation that is not a
+ *     status of its own: an evaluation that stops there feeds a Newton step that does not
+ *     converge, which ends in status 1; the sweep total is in the high half of `iters`.
  */
 #ifndef OEI_HIP_H
 #define OEI_HIP_H

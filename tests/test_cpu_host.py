@@ -188,3 +188,17 @@ def test_bench_candidate_blocks_tile_the_global_array():
     assert np.array_equal(full, np.random.RandomState(5).uniform(-.5, .5, (300, 4, 3)))
     for lo, hi in [(0, 100), (100, 200), (37, 38), (250, 300)]:
         assert np.array_equal(bench.candidate_block(300, 4, 3, 5, lo, hi, chunk=64), full[lo:hi])
+
+
+def test_built_library_keeps_scalar_spill_carriers_in_registers():
+    """A kernel that parks spilled scalar registers in vector-register lanes and then writes those
+    carrier registers to scratch memory was observed to compute wrong results (padded Q = 32 solver
+    instance, q = 21..31).  The shipped library must not contain that pattern
+    (tools/check_spills.py disassembles every embedded gfx950 code object)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_spills
+    from bayesian_optimization_amd import _lib
+    bad, total = check_spills.scan(_lib.LIB_PATH)
+    assert total > 40
+    assert not bad, bad

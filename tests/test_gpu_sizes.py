@@ -56,6 +56,24 @@ def test_value_grad_size_classes(cuda, q):
     _check_batch(om, dm, Xs)
 
 
+@pytest.mark.parametrize('q', list(range(17, 33)))
+def test_padded_q32_instance_every_size(cuda, q):
+    """Every q served by the Q = 32 solver instance (padded for q < 32), through the stand-alone
+    SDP entry point and the fused value+gradient path: the status word is one the solver can
+    return, the iteration counts are those of a converging Newton iteration, and the results match
+    the oracle.  (A build whose compiler spilled the carrier registers of scalar spills returned
+    61 Newton iterations and values off by 5e-3 for q = 21..31.)"""
+    from bayesian_optimization_amd import sdp_batched
+    om, dm = _mk(60)
+    Xs = np.random.RandomState(31 + q).uniform(-.5, .5, (3, q, 6))
+    omg = dm.omega(Xs)
+    value, M, Y, status, iters = sdp_batched(omg, dm.fmin)
+    status, iters = status.cpu().numpy(), iters.cpu().numpy()
+    assert set(status.tolist()) <= {0, 1, 2} and (status == 0).all(), status
+    assert ((iters & 0xffff) <= 8).all() and ((iters >> 16) <= 40).all(), (iters & 0xffff, iters >> 16)
+    _check_batch(om, dm, Xs)
+
+
 @pytest.mark.parametrize('q,d,n', [(1, 1, 5), (1, 6, 20), (2, 11, 30), (3, 12, 40), (5, 7, 65),
                                    (15, 8, 129), (16, 2, 64), (31, 9, 100), (32, 5, 200),
                                    (33, 11, 70), (64, 3, 90)])
