@@ -30,6 +30,7 @@ SIGNATURES = {
     'oei_solution_derivative_batched': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                        vp, vp, vp, vp, vp, vp, vp, vp]),
     'oei_value_grad_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
+    'oei_value_grad_warm_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oei_value_grad_batched_noalloc': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
     'oei_hessian_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     'oei_domega_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),

@@ -291,7 +291,10 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
                                               double* __restrict__ value, int* __restrict__ status,
                                               double* __restrict__ p_out,
                                               double* __restrict__ M11_out,
-                                              double* __restrict__ Z) {
+                                              double* __restrict__ Z,
+                                              const double* __restrict__ start_in,
+                                              double* __restrict__ start_out,
+                                              int* __restrict__ iters_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     SdpWork w;
     sdp_carve(w, sm, q, false);
@@ -309,7 +312,9 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     __syncthreads();
     double g = 0.0;
     int it = 0;
-    const int st = sdp_solve<T, Q>(w, &g, &it);
+    const int st = sdp_solve<T, Q>(w, &g, &it, start_in ? start_in + (size_t)b * q : nullptr,
+                                   start_out ? start_out + (size_t)b * q : nullptr);
+    if (iters_out && tid == 0) iters_out[b] = it;
     double* Zrows = Z + (size_t)b * q * npad;
     if (st == 2) {
         if (tid == 0) { value[b] = NAN; status[b] = 2; }
@@ -586,7 +591,8 @@ static int set_lds(K kernel, size_t lds) {
 // moments + SDP + Z for B candidates whose A rows sit at A + b*a_cand_stride + a*a_row_stride.
 int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
                       size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
-                      double* p_buf, double* M11_buf, double* Z, hipStream_t st) {
+                      double* p_buf, double* M11_buf, double* Z, hipStream_t st,
+                      const double* start_in, double* start_out, int* iters) {
     int rc;
     if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("stage2: q=%d exceeds the per-thread accumulator budget", q);
@@ -595,7 +601,7 @@ int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const d
 #define LAUNCH_STAGE2(T_, Q_) do { \
         const size_t lds2 = acq_lds_doubles(q, m->d, (Q_) == 0) * sizeof(double); \
         if ((rc = set_lds(k_stage2<T_, Q_>, lds2))) return rc; \
-        hipLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z); } while (0)
+        hipLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z, start_in, start_out, iters); } while (0)
     SDP_DISPATCH_Q(q, LAUNCH_STAGE2);
 #undef LAUNCH_STAGE2
     OEI_HIP_CHECK(hipGetLastError());
@@ -647,7 +653,8 @@ static inline size_t value_grad_aux_doubles(const oei_model* m, int B, int q) {
 // in here allocates.
 static int value_grad_run(oei_model* m, int B, int q, const double* X, double* value, double* grad,
                           int* status, int* flags, hipStream_t st, double* ws0, double* ws1,
-                          double* ws2, double* aux) {
+                          double* ws2, double* aux, const double* start_in = nullptr,
+                          double* start_out = nullptr, int* iters = nullptr) {
     int rc;
     const int d = m->d;
     const size_t rows = (size_t)B * q, rows_pad = round_up(rows, 64);
@@ -667,7 +674,7 @@ static int value_grad_run(oei_model* m, int B, int q, const double* X, double* v
         oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
         return OEI_ERR_ARG;
     }
-    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, ws0, st);
+    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, ws0, st, start_in, start_out, iters);
     if (rc) return rc;
     if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
         OEI_HIP_CHECK(hipMemsetAsync(ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
@@ -733,6 +740,20 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     if ((rc = oei_ws_reserve(m, rows_pad, value_grad_aux_doubles(m, B, q) * sizeof(double)))) return rc;
     if ((rc = oei_ws2_reserve(m, rows_pad))) return rc;
     return value_grad_run(m, B, q, X, value, grad, status, flags, (hipStream_t)stream, m->ws0, m->ws1, m->ws2, m->aux);
+}
+
+extern "C" int oei_value_grad_warm_batched(oei_model* m, int B, int q, const double* X, double* value,
+                                           double* grad, int* status, int* flags,
+                                           const double* start_in, double* start_out, int* iters, void* stream) {
+    int rc = check_model_call(m, B, q, X, "value_grad_warm_batched");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    if (!value || !grad || !status) { oei_set_error("value_grad_warm_batched: null output"); return OEI_ERR_ARG; }
+    const size_t rows_pad = round_up((size_t)B * q, 64);
+    if ((rc = oei_ws_reserve(m, rows_pad, value_grad_aux_doubles(m, B, q) * sizeof(double)))) return rc;
+    if ((rc = oei_ws2_reserve(m, rows_pad))) return rc;
+    return value_grad_run(m, B, q, X, value, grad, status, flags, (hipStream_t)stream, m->ws0, m->ws1, m->ws2, m->aux,
+                          start_in, start_out, iters);
 }
 
 extern "C" int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const double* X, double* value,

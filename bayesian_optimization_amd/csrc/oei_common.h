@@ -115,7 +115,8 @@ int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int 
                         hipStream_t st);
 int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
                       size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
-                      double* p_buf, double* M11_buf, double* Z, hipStream_t st);
+                      double* p_buf, double* M11_buf, double* Z, hipStream_t st,
+                      const double* start_in = nullptr, double* start_out = nullptr, int* iters = nullptr);
 // G_b = E_b E_b^T (lower block-triangle of 64x64 tiles), E [B*RP, npad], G [B, RP, RP].
 int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st);
 // C[r, j] = sum_k A[r, k] * Bm[j, k], all [*, npad] row-major; `lower` != 0 means Bm is lower

@@ -173,10 +173,11 @@ __device__ __forceinline__ double gsym(const double* __restrict__ Gb, int RP, in
 
 // mu[a], DS[a][l][b] = d Sigma_ab / d x_al (b == a: the full derivative of Sigma_aa),
 // dmuT[a][l] = d mu_a / d x_al, k1s[a][b] = 2 var kappa'(t_ab), k2s[a][b] = 4 var kappa''(t_ab).
-template <int T>
+// TP: where the q^2-sized tables live -- lds_f64* (q <= 32) or double* (global memory, q > 32).
+template <int T, typename TP>
 __device__ __forceinline__ void build_tables(const KernParams& kp, int q, const lds_f64* xq,
-                             const double* __restrict__ Gb, int RP, lds_f64* mu, lds_f64* DS,
-                             lds_f64* dmuT, lds_f64* k1s, lds_f64* k2s) {
+                             const double* __restrict__ Gb, int RP, lds_f64* mu, TP DS,
+                             lds_f64* dmuT, TP k1s, TP k2s) {
     const int tid = threadIdx.x, d = kp.d, dp = d + 1, vrow = q * dp;
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, b = e - a * q;
@@ -205,35 +206,58 @@ __device__ __forceinline__ void build_tables(const KernParams& kp, int q, const 
     __syncthreads();
 }
 
-// ---- domega (oei.py:125-135): dense [k_, k_, q*d] from the tables --------------------------------
+// ---- domega (oei.py:125-135): dense [k_, k_, q*d] -----------------------------------------------
+// Every non-zero entry needs one entry of dSigma/dx, which is formed on the spot from the Gram
+// block: no q*d*q table, so the kernel fits every q <= 64.
 template <int T>
 __global__ __launch_bounds__(T) void k_domega(KernParams kp, int q, int RP,
                                               const double* __restrict__ Xq,
                                               const double* __restrict__ G,
                                               double* __restrict__ domega) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int d = kp.d, qd = q * d, k_ = q + 1;
+    const int d = kp.d, dp = d + 1, qd = q * d, k_ = q + 1, vrow = q * dp;
     lds_f64* xq = (lds_f64*)sm;          // [q*d]
     lds_f64* mu = xq + qd;               // [q]
-    lds_f64* DS = mu + q;                // [q*d*q]
-    lds_f64* dmuT = DS + qd * q;         // [q*d]
+    lds_f64* dmuT = mu + q;              // [q*d]
     lds_f64* k1s = dmuT + qd;            // [q*q]
-    lds_f64* k2s = k1s + q * q;          // [q*q]
     const int tid = threadIdx.x;
     const size_t b = blockIdx.x;
+    const double* Gb = G + b * (size_t)RP * RP;
     for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
     __syncthreads();
-    build_tables<T>(kp, q, xq, G + b * (size_t)RP * RP, RP, mu, DS, dmuT, k1s, k2s);
+    for (int e = tid; e < q * q; e += T) {
+        const int a = e / q, c = e - a * q;
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - xq[c * d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        k1s[e] = (a == c) ? 0.0 : 2.0 * kp.variance * k1;
+    }
+    for (int a = tid; a < q; a += T) mu[a] = gsym(Gb, RP, vrow, a * dp);
+    for (int e = tid; e < qd; e += T) {
+        const int a = e / d, l = e - a * d;
+        dmuT[e] = gsym(Gb, RP, vrow, a * dp + 1 + l);
+    }
+    __syncthreads();
+    // d Sigma_ac / d x_al (c == a: the full derivative of Sigma_aa)
+    auto ds = [&](int a, int l, int c) -> double {
+        const double ta = gsym(Gb, RP, a * dp + 1 + l, c * dp);       // T_(a,l) . A_c
+        return (a == c) ? -2.0 * ta
+                        : k1s[a * q + c] * (xq[a * d + l] - xq[c * d + l]) * kp.inv_ls2[l] - ta;
+    };
     double* out = domega + b * (size_t)k_ * k_ * qd;
     for (size_t e = tid; e < (size_t)k_ * k_ * qd; e += T) {
         const int ij = (int)(e / qd), al = (int)(e - (size_t)ij * qd);
         const int i = ij / k_, j = ij - i * k_, a = al / d, l = al - a * d;
         double val = 0.0;
         if (i < q && j < q) {
-            if (i == j) { if (a == i) val = DS[(a * d + l) * q + a] + 2.0 * mu[a] * dmuT[al]; }
+            if (i == j) { if (a == i) val = ds(a, l, a) + 2.0 * mu[a] * dmuT[al]; }
             else {
-                if (a == i) val = DS[(a * d + l) * q + j] + dmuT[al] * mu[j];
-                else if (a == j) val = DS[(a * d + l) * q + i] + dmuT[al] * mu[i];
+                if (a == i) val = ds(a, l, j) + dmuT[al] * mu[j];
+                else if (a == j) val = ds(a, l, i) + dmuT[al] * mu[i];
             }
         } else if (i < q) { if (a == i) val = dmuT[al]; }
         else if (j < q) { if (a == j) val = dmuT[al]; }
@@ -257,22 +281,16 @@ __host__ __device__ inline size_t hess_tab_doubles(int q, int d) {
     return ds > chunk ? ds : chunk;
 }
 
-__host__ __device__ inline size_t hess_lds_doubles(int q, int d) {
-    // SdpWork + mu[VL] + SensVec + xq + tables(DS | chunk) + dmuT + k1s + k2s + Dg + M11 + dNmu[VL]
-    return sdp_work_doubles(q, true) + (size_t)(1 + SENS_NVEC + 1) * sdp_vlen(q) + (size_t)q * d +
-           hess_tab_doubles(q, d) + (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
-}
 
 // Dg pre-pass: Dg_a[l][m] = sum_k (p_a alpha_k - 2 W[a,k]) d2k(x_a,X_k)/dx_al dx_am, training points
 // staged in `tab` in chunks.  T threads; leaves a barrier behind.
-template <int T>
+template <int T, typename DP>
 __device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int npad, int q,
                                                 const lds_f64* xq, const lds_f64* pv, lds_f64* tab,
-                                                lds_f64* Dg, const double* __restrict__ Xtrain,
+                                                size_t tabsz, DP Dg, const double* __restrict__ Xtrain,
                                                 const double* __restrict__ alpha,
                                                 const double* __restrict__ Wrows) {
     const int tid = threadIdx.x, d = kp.d, dl = (d + 1) | 1;
-    const size_t tabsz = hess_tab_doubles(q, d);
     int ch = (int)((tabsz - 2 * q) / (2 * q + dl));
     ch = (ch / 16) * 16;
     if (ch > 64) ch = 64;
@@ -330,10 +348,9 @@ __device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int
 }
 
 // self-covariance part of Dg: 2 sum_{c != a} M11_ac Hs_ac
-template <int T>
+template <int T, typename MP, typename TP, typename DP>
 __device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, const lds_f64* xq,
-                                                const lds_f64* M11, const lds_f64* k1s,
-                                                const lds_f64* k2s, lds_f64* Dg) {
+                                                MP M11, TP k1s, TP k2s, DP Dg) {
     const int d = kp.d;
     for (int e = threadIdx.x; e < q * d * d; e += T) {
         const int a = e / (d * d), rem = e - a * d * d, l = rem / d, m2 = rem - l * d;
@@ -350,14 +367,15 @@ __device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, con
 
 // Row (a,l) of the Hessian from the direction's dN (q x LD), w1, w2, dN mu: the contraction with
 // every dOmega_(b,m) plus d2<Omega,M>/dx2 at fixed M.  `nth` threads numbered `tid` share the row.
+template <typename MP, typename TP>
 __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams& kp, int q, int RP,
                                               int a, int l, const lds_f64* dN, int LD,
-                                              const lds_f64* DS, const lds_f64* dmuT,
+                                              TP DS, const lds_f64* dmuT,
                                               const lds_f64* w1, const lds_f64* w2,
                                               const lds_f64* dNmu, const double* __restrict__ Gb,
-                                              const lds_f64* M11, const lds_f64* xq,
-                                              const lds_f64* k1s, const lds_f64* k2s,
-                                              const lds_f64* Dg, double* __restrict__ Hb,
+                                              MP M11, const lds_f64* xq,
+                                              TP k1s, TP k2s,
+                                              TP Dg, double* __restrict__ Hb,
                                               const double* ttpre = nullptr) {
     const int d = kp.d, dp = d + 1, qd = q * d, al = a * d + l;
     int pass = 0;
@@ -365,7 +383,7 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
         const int bb = bm / d, m2 = bm - bb * d;
         // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
         double acc = 0.0;
-        const lds_f64* dsrow = DS + (size_t)bm * q;
+        const auto dsrow = DS + (size_t)bm * q;
 #pragma unroll 4
         for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
         double P = -acc + 2.0 * dmuT[bm] * (w1[bb] + w2[bb] - dNmu[bb]);
@@ -386,46 +404,70 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
     }
 }
 
-template <int T, int Q>
-__global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double fmin, int n,
-                                            int npad, int q, int RP,
-                                            const double* __restrict__ Xtrain,
-                                            const double* __restrict__ alpha,
-                                            const double* __restrict__ Xq,
-                                            const double* __restrict__ G,
-                                            const double* __restrict__ Wm,
-                                            const double* __restrict__ p_in,
-                                            const double* __restrict__ M11_in,
-                                            double* __restrict__ Hout, int* __restrict__ status) {
+// ---- q > 32: one 256-thread workgroup per candidate ------------------------------------------------
+// LDS holds four q x q matrices (Newton factor, U and two scratch matrices; R is expressed through
+// U, see sens_direction_lean), the solver's vectors, the candidate's points and d mu/dx.  The
+// q^2-sized tables (dSigma/dx: q*d*q doubles, the kernel-derivative factors, the diagonal blocks
+// Dg) live in a per-candidate block of global memory `tabs`; they are written once, then read
+// row-wise by the contraction of every direction (L2-resident).  Fits every q <= 64 for d <= 12.
+__host__ __device__ inline size_t hess_wide_table_doubles(int q, int d) {
+    return (size_t)q * d * q + 2 * (size_t)q * q + (size_t)q * d * d;      // DS | k1s | k2s | Dg
+}
+__host__ __device__ inline size_t hess_wide_lds_doubles(int q, int d) {
+    // H S X V | 15 solver vectors + 8 scalars | mu, 9 sensitivity vectors, dNmu, vr, wv, scl | xq | dmuT
+    return (size_t)4 * q * sdp_ld(q) + (size_t)(SDP_NVEC + 1 + SENS_NVEC + 4) * sdp_vlen(q) + 8 + 2 * (size_t)q * d;
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, double fmin, int n,
+                                                 int npad, int q, int RP,
+                                                 const double* __restrict__ Xtrain,
+                                                 const double* __restrict__ alpha,
+                                                 const double* __restrict__ Xq,
+                                                 const double* __restrict__ G,
+                                                 const double* __restrict__ Wm,
+                                                 const double* __restrict__ p_in,
+                                                 const double* __restrict__ M11_in,
+                                                 const int* __restrict__ sdp_status,
+                                                 double* tabs,
+                                                 double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int VL = sdp_vlen(q), LD = sdp_ld(q), ML = q * LD, d = kp.d, dp = d + 1, qd = q * d;
     SdpWork w;
-    sdp_carve(w, sm, q, true);
-    const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d, dl = (d + 1) | 1;
-    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, true);
+    w.q = q; w.LD = LD;
+    lds_f64* ptr = (lds_f64*)sm;
+    w.H = ptr; ptr += ML;  w.S = ptr; ptr += ML;  w.X = ptr; ptr += ML;  w.V = ptr; ptr += ML;
+    w.R = w.Kt = nullptr;
+    w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
+    w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
+    w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;  w.ip = ptr; ptr += VL;
+    w.wp = ptr; ptr += VL; w.rc = ptr; ptr += VL;  w.rs = ptr; ptr += VL;
+    w.scal = ptr; ptr += 8;
+    lds_f64* mu = ptr; ptr += VL;
     SensVec sv;
-    sens_carve(sv, mu + VL, q);
-    lds_f64* dNmu = mu + VL + SENS_NVEC * VL;    // [VL]
-    lds_f64* xq = dNmu + VL;                     // [q*d]
-    lds_f64* tab = xq + qd;                      // DS [q*d*q], first used as chunk staging
-    lds_f64* dmuT = tab + hess_tab_doubles(q, d);
-    lds_f64* k1s = dmuT + qd;
-    lds_f64* k2s = k1s + q * q;
-    lds_f64* M11 = k2s + q * q;
-    lds_f64* Dg = M11 + q * q;                   // [q][d][d]
+    sens_carve(sv, ptr, q); ptr += SENS_NVEC * VL;
+    lds_f64* dNmu = ptr; ptr += VL;
+    lds_f64* vr = ptr; ptr += VL;
+    lds_f64* wv = ptr; ptr += VL;
+    lds_f64* scl = ptr; ptr += VL;
+    lds_f64* xq = ptr; ptr += qd;
+    lds_f64* dmuT = ptr;
     const int tid = threadIdx.x;
     const size_t b = blockIdx.x;
     const double* Gb = G + b * (size_t)RP * RP;
+    const double* M11 = M11_in + b * (size_t)q * q;
     double* Hb = Hout + b * (size_t)qd * qd;
+    double* DS = tabs + b * hess_wide_table_doubles(q, d);
+    double* k1s = DS + (size_t)qd * q;
+    double* k2s = k1s + (size_t)q * q;
+    double* Dg = k2s + (size_t)q * q;
     for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
-    for (int e = tid; e < q * q; e += T) M11[e] = M11_in[b * q * q + e];
     if (tid < q) w.p[tid] = p_in[b * q + tid];
     __syncthreads();
 
-    hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, tab, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
-
-    // ---- tables, moments, state at the optimum --------------------------------------------------
-    build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
-    lds_f64* DS = tab;
+    // w.X and w.V (adjacent) stage the training-point chunks of the Dg pre-pass
+    hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, w.X, (size_t)2 * ML, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    build_tables<T>(kp, q, xq, Gb, RP, mu, DS, dmuT, k1s, k2s);
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, c = e - a * q;
         double t = 0.0;
@@ -438,42 +480,51 @@ __global__ __launch_bounds__(T) void k_hess(KernParams kp, double noise, double 
         w.S[a * LD + c] = kp.variance * k0 - gsym(Gb, RP, a * dp, c * dp) + (a == c ? noise : 0.0);
     }
     if (tid < q) w.dl[tid] = mu[tid] - fmin;
-    hess_dg_selfcov<T>(kp, q, xq, M11, k1s, k2s, Dg);
+    hess_dg_selfcov<T>(kp, q, xq, M11, (const double*)k1s, (const double*)k2s, Dg);
     __syncthreads();
+
+    // ---- state at the optimum: U, the factor of -hess g, c, t1 ----------------------------------
     int sweeps = 0;
-    int st = sdp_factor<T, Q>(w) ? 2 : 0;
-    const double g = st ? -INFINITY : sdp_eval<T, Q>(w, w.p, sweeps, false);
+    int st = sdp_factor<T, 0>(w) ? 2 : 0;
+    const double g = st ? -INFINITY : sdp_eval<T, 0>(w, w.p, sweeps, false);
     if (!(g > -INFINITY)) st = 2;
-    if (!st && sens_prepare<T, Q>(w, mu, sv)) st = 2;
+    if (!st) {
+        if (sdp_newton_dir<T, 0>(w)) st = 2;          // reads U from w.X; w.S (Lc) is free afterwards
+    }
     if (st) {
         for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
         if (tid == 0 && status) status[b] = 2;
         return;
     }
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {
+        const int i = e / q, a = e - i * q;
+        w.S[i * LD + a] = w.X[i * LD + a];
+    }
+    if (tid < q) {
+        double acc = 0.0;                             // c = mu + R (sq o rp)
+        for (int a = 0; a < q; ++a) acc += sdp_R(w, tid, a) * w.sq[a] * w.rp[a];
+        sv.c[tid] = mu[tid] + acc;
+        sv.t1[tid] = w.sq[tid] * w.rp[tid];
+        w.rc[tid] = 1.0 / w.H[tid * LD + tid];
+    }
+    __syncthreads();
 
     // ---- one sensitivity solve per direction, fused with the contraction ------------------------
     for (int al = 0; al < qd; ++al) {
         const int a = al / d, l = al - a * d;
         __syncthreads();
-        if (tid < q) sv.dmu[tid] = (tid == a) ? dmuT[al] : 0.0;
-        for (int e = tid; e < q * q; e += T) {
-            const int i = e / q, j = e - i * q;
-            double val = 0.0;
-            if (i == a) val = DS[al * q + j];
-            else if (j == a) val = DS[al * q + i];
-            w.X[i * LD + j] = val;
-        }
-        const double dnu = sens_direction<T, false, false>(w, sv, SensDir{0, nullptr, nullptr, nullptr, nullptr});
-        (void)dnu;
         if (tid < q) {
-            double acc = 0.0;
-            for (int c = 0; c < q; ++c) acc += w.X[tid * LD + c] * mu[c];
-            dNmu[tid] = acc;
+            sv.dmu[tid] = (tid == a) ? dmuT[al] : 0.0;
+            vr[tid] = DS[(size_t)al * q + tid];
         }
+        sens_direction_lean<T>(w, sv, a, vr, wv, scl);
+        if (tid < q) dNmu[tid] = lds_dot(w.X + tid * LD, 1, mu, 1, q);
         __syncthreads();
-        hess_contract(tid, T, kp, q, RP, a, l, w.X, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq, k1s, k2s, Dg, Hb);
+        hess_contract(tid, T, kp, q, RP, a, l, w.X, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
+                      (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
     }
-    if (tid == 0 && status) status[b] = 0;
+    if (tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
 }
 
 // ---- register-path sizes (q <= 32): the same work in two kernels ---------------------------------
@@ -570,6 +621,7 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
                                                  const double* __restrict__ M11_in,
                                                  const double* __restrict__ state,
                                                  const int* __restrict__ stflag,
+                                                 const int* __restrict__ sdp_status,
                                                  double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int NW = T / 64;
@@ -607,10 +659,10 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         for (int e = tid; e < 5 * VL; e += T) rc[e] = sb[3 * ML + e];     // rc sq rp c t1 likewise
     }
     __syncthreads();
-    hess_dg_prepass<T>(kp, n, npad, q, xq, pv, tab, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    hess_dg_prepass<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
     build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
     const lds_f64* DS = tab;
-    hess_dg_selfcov<T>(kp, q, xq, M11, k1s, k2s, Dg);
+    hess_dg_selfcov<T>(kp, q, xq, (const lds_f64*)M11, k1s, k2s, Dg);
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, c = e - a * q;
         const double sa = sq[a], sc = sq[c];
@@ -645,9 +697,11 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         sens_direction<64, true, true, QE>(w, sv, SensDir{a, DS + (size_t)al * q, wvec, phiS, phiD});
         if (lane < q) dNmu[lane] = lds_dot(w.X + lane * LD, 1, mu, 1, q);
         sens_sync<true>();
-        hess_contract(lane, 64, kp, q, RP, a, l, w.X, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq, k1s, k2s, Dg, Hb, ttpre);
+        hess_contract(lane, 64, kp, q, RP, a, l, w.X, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, (const lds_f64*)M11, xq,
+                      (const lds_f64*)k1s, (const lds_f64*)k2s, (const lds_f64*)Dg, Hb, ttpre);
     }
-    if (tid == 0 && status) status[b] = 0;
+    // a solve that stopped at the Newton iteration limit (status 1) still gets its Hessian
+    if (tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -691,7 +745,7 @@ extern "C" int oei_domega_batched(oei_model* m, int B, int q, const double* X, d
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d, qd = q * d, k_ = q + 1;
     const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
-    const size_t lds = ((size_t)2 * qd + q + (size_t)qd * q + 2 * (size_t)q * q) * sizeof(double);
+    const size_t lds = ((size_t)2 * qd + q + (size_t)q * q) * sizeof(double);
     const int chunk = 512;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = (B - b0 < chunk) ? B - b0 : chunk;
@@ -718,18 +772,20 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d, qd = q * d, npad = m->npad;
     const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
-    const size_t lds = hess_lds_doubles(q, d) * sizeof(double);
+    const size_t lds = hess_wide_lds_doubles(q, d) * sizeof(double);     // q > 32 only
     // candidates per pass: bounded by the per-candidate workspace (E rows and Gram block, about
     // 2 * RP * (npad + RP / 2) doubles), 2048 when that stays below ~4 GB
     int chunk = 2048;
-    while (chunk > 64 && (double)chunk * RP * (2.0 * npad + RP) * sizeof(double) > 4e9) chunk /= 2;
+    const double per_cand = (double)RP * (2.0 * npad + RP) + (q > 32 ? (double)hess_wide_table_doubles(q, d) : 0.0);
+    while (chunk > 64 && (double)chunk * per_cand * sizeof(double) > 4e9) chunk /= 2;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = (B - b0 < chunk) ? B - b0 : chunk;
         const double* Xc = X + (size_t)b0 * qd;
         const size_t zrows = round_up_sz((size_t)Bc * q, 64);
         const size_t zbytes = zrows * npad * sizeof(double);
         const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
-        const size_t sbytes = (q <= 32) ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16 : 0;
+        const size_t sbytes = (q <= 32) ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16
+                                        : (size_t)Bc * hess_wide_table_doubles(q, d) * sizeof(double) + 16;
         if ((rc = hess_front(m, Bc, q, Xc, RP, 2 * zbytes + Bc * sizeof(double) + ((Bc + 1) & ~1) * sizeof(int) + sbytes, st))) return rc;
         double* Zb = m->hs + gbytes / sizeof(double);
         double* Wb = Zb + zrows * npad;
@@ -760,15 +816,16 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
 #define LAUNCH_DIRS(TT, QE) do { \
                 const size_t lds_d = shared + (size_t)((TT) / 64) * per_wave; \
                 if ((rc = set_lds_attr((k_hess_dirs<TT, QE>), lds_d))) return rc; \
-                hipLaunchKernelGGL((k_hess_dirs<TT, QE>), dim3(Bc), dim3(TT), lds_d, st, m->kp, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, state, pflag, Hc, sc); } while (0)
+                hipLaunchKernelGGL((k_hess_dirs<TT, QE>), dim3(Bc), dim3(TT), lds_d, st, m->kp, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, state, pflag, stb, Hc, sc); } while (0)
             // (an instance specialised for q = 20 was measured slower: its straight-line code
             // spills 160 registers per lane, and the spill traffic costs more than the constants save)
             if (nw >= 8) LAUNCH_DIRS(512, 0); else if (nw >= 4) LAUNCH_DIRS(256, 0);
             else if (nw >= 2) LAUNCH_DIRS(128, 0); else LAUNCH_DIRS(64, 0);
 #undef LAUNCH_DIRS
         } else {
-            if ((rc = set_lds_attr((k_hess<256, 0>), lds))) return rc;
-            hipLaunchKernelGGL((k_hess<256, 0>), dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, Hc, sc);
+            double* tabs = reinterpret_cast<double*>(stb + ((Bc + 1) & ~1));
+            if ((rc = set_lds_attr((k_hess_wide<256>), lds))) return rc;
+            hipLaunchKernelGGL((k_hess_wide<256>), dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, stb, tabs, Hc, sc);
         }
         OEI_HIP_CHECK(hipGetLastError());
     }

@@ -1237,11 +1237,20 @@ __device__ __forceinline__ int sdp_newton_dir_s(const SdpWork w) {
     else return sdp_newton_dir_x<T, Q, EXACT>(w);
 }
 
+// `start_in` / `start_out` (global memory, q entries each, or null): solver start state carried from
+// a nearby problem to this one -- the role of the reference's warm start (sdp.py:77-121: nearest
+// past solution).  The state is the ratio of the optimal weights to the closed-form start weights
+// of the same problem; multiplied with this problem's closed-form weights it gives a start that
+// follows the first-order change of every point's own mean and variance, so it stays useful over
+// larger moves than the old weights themselves (which beat the closed form only for moves below
+// 1e-4 of the box).  Used when the product lies inside the simplex.
 template <int T, int Q, bool EXACT>
-__device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, int* iters_out) {
+__device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, int* iters_out,
+                                              const double* __restrict__ start_in = nullptr,
+                                              double* __restrict__ start_out = nullptr) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
-    // start: the closed-form q = 1 weights, shrunk into the simplex
+    // closed-form q = 1 weights, shrunk into the simplex
     if (tid < q) {
         const double d = w.dl[tid], s2 = w.S[tid * LD + tid];
         const double r = sqrt(s2 + d * d);
@@ -1251,7 +1260,21 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
     double tot = 0.0;
     for (int i = 0; i < q; ++i) tot += w.pn[i];
     __syncthreads();
-    if (tid < q) w.p[tid] = fmax(w.pn[tid] / (1.0 + tot), 1e-300);
+    const double pcf = (tid < q) ? fmax(w.pn[tid] / (1.0 + tot), 1e-300) : 0.0;
+    bool warm = false;
+    if (start_in) {                                      // uniform
+        const double v = (tid < q) ? start_in[tid] * pcf : 0.0;
+        const int inside = (tid < q) ? (v > 1e-300 && v < 1.0) : 1;      // false for NaN
+        if (tid < q) w.pn[tid] = inside ? v : 0.0;
+        warm = __syncthreads_and(inside) != 0;
+        double ws = 0.0;
+        for (int i = 0; i < q; ++i) ws += w.pn[i];
+        warm = warm && (ws < 1.0 - 1e-9);
+        __syncthreads();
+        if (tid < q) w.p[tid] = warm ? v : pcf;
+    } else {
+        if (tid < q) w.p[tid] = pcf;
+    }
     __syncthreads();
     int sweeps = 0, it = 0, status = 1;
 #ifdef OEI_SDP_TIMING
@@ -1264,7 +1287,8 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
     for (;;) {
         // evaluations that only steer the iteration run with the loose Jacobi tolerance; the one
         // after a step below the stopping tolerance is the final state and runs tight
-        const int mode = first ? (SDP_EVAL_LOOSE | SDP_EVAL_FIRST)
+        // (from a given starting point the first step may already be tiny: no early Jacobi exit)
+        const int mode = first ? (warm ? SDP_EVAL_LOOSE : (SDP_EVAL_LOOSE | SDP_EVAL_FIRST))
                                : (SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
         const double gv = sdp_eval_s<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
         if (first) {
@@ -1315,16 +1339,19 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
     }
     *g_out = g;
     *iters_out = (it & 0xffff) | (sweeps << 16);
+    if (start_out && tid < q) start_out[tid] = (status == 2) ? NAN : w.p[tid] / pcf;
     return status;
 }
 
 template <int T, int Q>
-__device__ __forceinline__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out) {
+__device__ __forceinline__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out,
+                                         const double* __restrict__ start_in = nullptr,
+                                         double* __restrict__ start_out = nullptr) {
     if constexpr (Q > 0) {
-        return (w.q == Q) ? sdp_solve_impl<T, Q, true>(w, g_out, iters_out)
-                          : sdp_solve_impl<T, Q, false>(w, g_out, iters_out);
+        return (w.q == Q) ? sdp_solve_impl<T, Q, true>(w, g_out, iters_out, start_in, start_out)
+                          : sdp_solve_impl<T, Q, false>(w, g_out, iters_out, start_in, start_out);
     } else {
-        return sdp_solve_impl<T, 0, false>(w, g_out, iters_out);
+        return sdp_solve_impl<T, 0, false>(w, g_out, iters_out, start_in, start_out);
     }
 }
 

@@ -331,3 +331,106 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     for (int i = 0; i < q; ++i) dnu += sv.c[i] * (2.0 * sv.w1[i] + sv.w2[i]);
     return dnu;
 }
+
+// The same direction for a whole workgroup when LDS is short (q > 32 in the Hessian kernel): R is
+// not stored but expressed through U, R = diag(1/p) U + 1 rp^T, so that four q x q matrices
+// suffice: U (w.S), the factor L of -hess g (w.H) and two scratch matrices (w.X, w.V).  With
+// t1 = sq o rp and M1' = ZS diag(sq) U^T:
+//   ZS diag(sq) R^T = M1' diag(1/p) + (ZS t1) 1^T,
+//   R^T diag(dp) R  = U^T diag(dp / p^2) U + h rp^T + rp h^T + (sum dp) rp rp^T,  h = U^T (dp / p),
+//   rd = R^T dp = h + (sum dp) rp,   so  R^T dD R = U^T diag(dp / p^2) U - (sum dp) rp rp^T.
+// In: sv.dmu and the perturbation in rank-2 form dS = e_a v'^T + v' e_a^T, v'_j = vr[j] (j != a),
+// v'_a = vr[a] / 2 (vr in LDS).  Out: dN in w.X, sv.w1 = N dc, sv.w2 = dN c, sv.dp.
+// Needs w.rc = 1 / diag(L), w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1; wv and scl are [q] scratch.
+template <int T>
+__device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensVec sv, int a_dir,
+                                                    const lds_f64* vr, lds_f64* wv, lds_f64* scl) {
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = w.LD;
+    const lds_f64* U = w.S;
+    lds_f64* Tc = w.X;
+    lds_f64* Tb = w.V;
+    __syncthreads();
+    if (tid < q) {
+        const double acc = lds_dot(U + tid, LD, vr, 1, q);
+        wv[tid] = acc - 0.5 * U[a_dir * LD + tid] * vr[a_dir];
+    }
+    __syncthreads();
+    {
+        const lds_f64* ua = U + a_dir * LD;
+        for (int e = tid; e < q * q; e += T) {                 // ZS
+            const int a = e / q, b = e - a * q;
+            const double sa = w.sq[a], sb = w.sq[b];
+            Tc[a * LD + b] = (ua[a] * wv[b] + wv[a] * ua[b]) * (-0.5 * sdp_rcp(sa * sb * (sa + sb)));
+        }
+    }
+    __syncthreads();
+    lds_mm<T, false, true, true>(q, LD, Tc, U, Tb, w.sq);      // Tb = M1' = ZS diag(sq) U^T
+    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);
+    __syncthreads();
+    if (tid < q) {
+        // rhs_i = dmu_i + sum_a R[i][a] sq[a] (M1[a][i] - 2 t2[a]),  M1[a][i] = M1'[a][i] / p_i + t2[a]
+        const double ipi = w.ip[tid];
+        double acc = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double r = fma(U[tid * LD + a], ipi, w.rp[a]);
+            acc = fma(r * w.sq[a], fma(ipi, Tb[a * LD + tid], -sv.t2[a]), acc);
+        }
+        w.step[tid] = sv.dmu[tid] + acc;
+    }
+    __syncthreads();
+    for (int k = 0; k < q; ++k) {                              // L y = rhs
+        const double yk = w.step[k] * w.rc[k];
+        __syncthreads();
+        if (tid == k) w.step[k] = yk;
+        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
+        __syncthreads();
+    }
+    for (int k = q - 1; k >= 0; --k) {                         // L^T x = y
+        const double xk = w.step[k] * w.rc[k];
+        __syncthreads();
+        if (tid == k) w.step[k] = xk;
+        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
+        __syncthreads();
+    }
+    if (tid < q) {
+        const double dp = -w.step[tid], ipi = w.ip[tid];
+        sv.dp[tid] = dp;
+        scl[tid] = dp * ipi * ipi;
+        wv[tid] = dp * ipi;                                    // wv is free again
+    }
+    __syncthreads();
+    double sdp = 0.0;
+    for (int i = 0; i < q; ++i) sdp += sv.dp[i];
+    if (tid < q) sv.rd[tid] = lds_dot(U + tid, LD, wv, 1, q) + w.rp[tid] * sdp;
+    lds_mm<T, true, false, true>(q, LD, U, U, Tb, scl);        // Tb = U^T diag(dp / p^2) U
+    __syncthreads();
+    for (int e = tid; e < q * q; e += T) {                     // Z = ZS + Phi o (R^T dD R) / 4
+        const int a = e / q, b = e - a * q;
+        const double acc = Tb[a * LD + b] - sdp * w.rp[a] * w.rp[b];
+        Tc[a * LD + b] += acc * (0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
+    }
+    __syncthreads();
+    lds_mm<T, false, true, false>(q, LD, Tc, U, Tb);           // Tb = Z U^T
+    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);        // Z t1
+    __syncthreads();
+    lds_mm<T, false, false, false>(q, LD, U, Tb, Tc);          // dN = U Z U^T replaces Z
+    if (tid < q) {
+        // dc = dmu + sum_a R[i][a] sq[a] (rd[a] - 2 t2[a])
+        const double ipi = w.ip[tid];
+        double acc = 0.0;
+        for (int a = 0; a < q; ++a) {
+            const double r = fma(U[tid * LD + a], ipi, w.rp[a]);
+            acc = fma(r * w.sq[a], fma(-2.0, sv.t2[a], sv.rd[a]), acc);
+        }
+        sv.dc[tid] = sv.dmu[tid] + acc;
+    }
+    __syncthreads();
+    if (tid < q) wv[tid] = lds_dot(U + tid, LD, sv.dc, 1, q) * sdp_rcp(w.sq[tid]);   // (U^T dc) / sq
+    __syncthreads();
+    if (tid < q) {
+        sv.w1[tid] = 0.5 * lds_dot(U + tid * LD, 1, wv, 1, q);          // N dc
+        sv.w2[tid] = lds_dot(Tc + tid * LD, 1, sv.c, 1, q);             // dN c
+    }
+    __syncthreads();
+}

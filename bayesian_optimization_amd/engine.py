@@ -146,6 +146,27 @@ class DeviceGP:
                   'oei_value_grad_batched_noalloc' if no_alloc else 'oei_value_grad_batched')
         return value, grad, status, flags
 
+    def value_grad_warm(self, X, p_init=None, want_iters=False):
+        """value_grad started from the solver state `p_init` [B,q] that a previous call returned
+        for a nearby X (None: the closed-form start).  Returns (value, grad, status, flags,
+        state [B,q], iters or None); feed `state` back as the next call's `p_init`.  The role of
+        the reference's SDP warm start (sdp.py:77-121) with the history kept by the caller."""
+        X = self._batch(X)
+        B, q, d = X.shape
+        value = torch.empty(B, dtype=torch.float64, device=self.device)
+        grad = torch.empty((B, q, d), dtype=torch.float64, device=self.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        flags = torch.empty(B, dtype=torch.int32, device=self.device)
+        p_out = torch.empty((B, q), dtype=torch.float64, device=self.device)
+        iters = torch.empty(B, dtype=torch.int32, device=self.device) if want_iters else None
+        if p_init is not None:
+            p_init = _dev_f64(p_init, self.device).reshape(B, q).contiguous()
+        with torch.cuda.device(self.device):
+            check(lib.oei_value_grad_warm_batched(self._h, B, q, _ptr(X), _ptr(value), _ptr(grad),
+                                                  _ptr(status), _ptr(flags), _ptr(p_init), _ptr(p_out),
+                                                  _ptr(iters), _stream()), 'oei_value_grad_warm_batched')
+        return value, grad, status, flags, p_out, iters
+
     def hessian(self, X):
         X = self._batch(X)
         B, q, d = X.shape

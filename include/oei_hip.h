@@ -105,6 +105,19 @@ int oei_solution_derivative_batched(int B, int k_, int K, const double* M, const
 int oei_value_grad_batched(oei_model* m, int B, int q, const double* X,
                            double* value, double* grad, int* status, int* flags, void* stream);
 
+/* The same evaluation started from the solver state of a nearby evaluation: the role of the
+ * reference's SDP warm start (sdp.py:41-48, 63-65, 77-121: history of past solutions, the nearest
+ * one extrapolated; bo.py:146 resets it per multistart).  Here the caller keeps the history:
+ * start_in device [B,q] or NULL holds, per candidate, the state a previous call wrote for a nearby X
+ * (opaque: the ratio of the optimal to the closed-form start weights; a NaN, or a product outside
+ * the simplex, means "no start" and the closed-form start is used); start_out device [B,q] or NULL
+ * receives this solve's state (may equal start_in); iters device int[B] or NULL the Newton
+ * iteration count (low 16 bits) and Jacobi sweeps (high bits).  The converged result does not
+ * depend on the start beyond the solver's tolerance (about 1e-10 relative on value and gradient). */
+int oei_value_grad_warm_batched(oei_model* m, int B, int q, const double* X,
+                                double* value, double* grad, int* status, int* flags,
+                                const double* start_in, double* start_out, int* iters, void* stream);
+
 /* The same evaluation for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
  * Identical arguments and results (bitwise) to oei_value_grad_batched, but the intermediates
@@ -117,10 +130,12 @@ int oei_value_grad_batched(oei_model* m, int B, int q, const double* X,
 int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const double* X,
                                    double* value, double* grad, int* status, int* flags, void* stream);
 
-/* acquisition_hessian (oei.py:41-64, 105-135): X device [B,q,d] -> H device [B,q*d,q*d].
- * The per-candidate tables live in LDS: every q <= 32 is served for d up to about 12 (q = 20) or
- * 7 (q = 32); above 32 only shapes with about (9 + d) q^2 doubles <= 160 KiB (q <= 36 at d = 6).
- * Larger shapes return OEI_ERR_ARG with the byte count in oei_last_error(). */
+/* acquisition_hessian (oei.py:41-64, 105-135): X device [B,q,d] -> H device [B,q*d,q*d],
+ * status device int[B] or NULL (that of the candidate's SDP solve).
+ * q <= 32: the per-candidate tables live in LDS, which serves d up to about 12 (q = 20) or 7
+ * (q = 32).  q > 32: the tables live in global memory and every q <= OEI_MAX_Q is served for
+ * d <= 12 (q = 50, d = 10 included).  Shapes beyond that return OEI_ERR_ARG with the byte count in
+ * oei_last_error(). */
 int oei_hessian_batched(oei_model* m, int B, int q, const double* X,
                         double* H, int* status, void* stream);
 

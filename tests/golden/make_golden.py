@@ -101,7 +101,33 @@ def make_oei_fixtures(only=None):
         print('oei_n%d_q%d: value %.12f' % (n, q, value))
 
 
+def make_hessian_cfg3():
+    """Rows 0, 10, 20, ... of the acquisition Hessian at the largest shape of the benchmark table
+    (n = 1000, q = 50, d = 10: the oracle needs minutes here, so the GPU test reads this fixture),
+    plus value and gradient."""
+    model = hart6.make_model(1000, d=10, lengthscale=0.8)
+    orc = ooei.OEIOracle(model)
+    X = np.random.RandomState(107).uniform(-0.5, 0.5, (50, 10))
+    assert len(orc.project(X)[0]) == 50
+    value, grad = orc.acquisition(X)
+    H = orc.acquisition_hessian(X.ravel())
+    assert np.abs(H - H.T).max() < 1e-10 * np.abs(H).max()
+    h = 1e-5                                   # finite-difference certification of two rows
+    for j in (0, 250):
+        e = np.zeros(500)
+        e[j] = h
+        gp_, gm_ = orc.acquisition(X.ravel() + e)[1], orc.acquisition(X.ravel() - e)[1]
+        assert np.abs((gp_ - gm_) / (2 * h) - H[j]).max() < 1e-5 * (1 + np.abs(H).max())
+    np.savez_compressed(os.path.join(HERE, 'hess_n1000_q50_d10.npz'), n=1000, q=50, d=10, lengthscale=0.8,
+                        X=X, value=value[0], gradient=grad, rows=np.arange(0, 500, 10), H_rows=H[::10],
+                        H_diag=np.diag(H).copy(), H_absmax=np.abs(H).max())
+    print('hess_n1000_q50_d10: value %.12f' % value[0])
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['cfg3-hessian']:
+        make_hessian_cfg3()
+        sys.exit(0)
     # optional arguments "n,q" restrict the run to those fixtures
     sel = [tuple(int(v) for v in a.split(',')) for a in sys.argv[1:]]
     main(sel or None)

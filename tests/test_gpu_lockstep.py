@@ -94,3 +94,52 @@ def test_lockstep_large_batch_device_resident(cuda):
     assert res.x.device.type == 'cuda'
     assert bool((res.fun <= v0 + 1e-12).all())
     assert float(best[0]) == float(res.fun.min())
+
+
+def test_warm_started_solve_matches_cold(cuda):
+    """oei_value_grad_warm_batched: a solve started from the weights of a nearby evaluation
+    (the role of sdp.py:77-121) returns the cold-start result to 1e-10 and needs fewer Newton
+    iterations; weights outside the simplex or NaN fall back to the closed-form start."""
+    from bayesian_optimization_amd import DeviceGP
+    model = hart6.make_model(310)
+    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    rs = np.random.RandomState(13)
+    X = torch.as_tensor(rs.uniform(-.45, .45, (256, 20, 6)), device=cuda)
+    v0, g0, st0, fl0, p0, it0 = gp.value_grad_warm(X, want_iters=True)
+    cold = gp.value_grad(X)
+    assert torch.equal(v0, cold[0]) and torch.equal(g0, cold[1])            # no start = the ordinary call
+    X1 = X + 1e-3 * torch.as_tensor(rs.randn(256, 20, 6), device=cuda)       # a line-search-sized move
+    vc, gc, stc, _, pc, itc = gp.value_grad_warm(X1, want_iters=True)
+    vw, gw, stw, _, pw, itw = gp.value_grad_warm(X1, p_init=p0, want_iters=True)
+    assert int((stc != 0).sum()) == 0 and int((stw != 0).sum()) == 0
+    assert float(((vw - vc).abs() / vc.abs()).max()) <= 1e-10
+    assert float((gw - gc).abs().max() / gc.abs().max()) <= 2e-9         # task bar: 1e-4
+    assert float((pw - pc).abs().max()) <= 1e-7                          # states (weight ratios)
+    nc, nw = (itc & 0xffff).double().mean().item(), (itw & 0xffff).double().mean().item()
+    assert nc >= 3.0 and nw <= 2.3, (nc, nw)
+    # unusable starts: NaN, outside (0, 1), sum >= 1
+    bad = p0.clone()
+    bad[0] = float('nan')
+    bad[1, 3] = -0.1
+    bad[2] = 0.06
+    vb = gp.value_grad_warm(X, p_init=bad)[0]
+    assert float(((vb - v0).abs() / v0.abs()).max()) <= 1e-10
+
+
+def test_lockstep_with_warm_start(cuda):
+    """The lock-step optimiser can thread every run's solver state through its evaluations: same
+    quality of optima as with cold starts, and no more Newton iterations per evaluation (the
+    quasi-Newton steps are mostly too long for the state to beat the closed-form start; the gain
+    shows for short moves, see test_warm_started_solve_matches_cold)."""
+    from bayesian_optimization_amd import DeviceGP, lockstep
+    model = hart6.make_model(310)
+    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    starts = torch.as_tensor(np.random.RandomState(9).uniform(-.5, .5, (256, 20, 6)), device=cuda)
+    sw, sc = {}, {}
+    rw, bw = lockstep.optimize_multistart(gp, starts, [-0.5] * 6, [0.5] * 6, max_iter=30, warm_start=True, stats=sw)
+    rc, bc = lockstep.optimize_multistart(gp, starts, [-0.5] * 6, [0.5] * 6, max_iter=30, warm_start=False, stats=sc)
+    assert sw['newton'] / sw['evals'] <= 3.3
+    # the iterates of the two runs differ at rounding level and the descent amplifies that:
+    # compare what the multistart keeps, the best value
+    assert abs(float(bw[0]) - float(bc[0])) <= 2e-2 * abs(float(bc[0]))
+    assert float((rw.fun - rc.fun).abs().median()) <= 1e-2

@@ -26,8 +26,11 @@ torch.cuda.synchronize(); t_lock = time.perf_counter() - t0
 print('20 starts: sequential %.2f s (%d evaluations, best %.6f); lock-step %.2f s (max %d evaluations per run, best %.6f)'
       % (t_seq, nfev, min(seq), t_lock, int(res.nfev.max()), float(best[0])))
 big = np.random.RandomState(4).uniform(-.5, .5, (2048, q, 6))
-torch.cuda.synchronize(); t0 = time.perf_counter()
-res, best = lockstep.optimize_multistart(gp, big, [-.5] * 6, [.5] * 6)
-torch.cuda.synchronize(); t_big = time.perf_counter() - t0
-print('2048 starts lock-step: %.2f s, %d evaluations in total, best %.6f, converged %d'
-      % (t_big, int(res.nfev.sum()), float(best[0]), int(res.converged.sum())))
+for warm in (False, True):
+    st = {}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res, best = lockstep.optimize_multistart(gp, big, [-.5] * 6, [.5] * 6, warm_start=warm, stats=st)
+    torch.cuda.synchronize(); t_big = time.perf_counter() - t0
+    print('2048 starts lock-step, SDP warm start %s: %.2f s, %d evaluations in total, Newton iterations per evaluation %s, best %.6f, converged %d'
+          % (warm, t_big, int(res.nfev.sum()), ('%.2f' % (st['newton'] / st['evals'])) if 'newton' in st else 'n/a (3.2 cold)',
+             float(best[0]), int(res.converged.sum())))
