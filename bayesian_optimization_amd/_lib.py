@@ -37,6 +37,7 @@ SIGNATURES = {
     'oei_set_profiling': (ctypes.c_int, [vp, ctypes.c_int]),
     'oei_get_stage_times': (ctypes.c_int, [vp, vp]),
     'oei_argmin': (ctypes.c_int, [ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp]),
+    'oei_best_record': (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_longlong, vp, vp]),
     'oei_model_nlml': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
 }
 

@@ -560,6 +560,40 @@ __global__ __launch_bounds__(1024) void k_argmin(int B, const double* __restrict
     }
 }
 
+// The same arg-min, leaving the whole (value, index, X) record of the winner in one buffer:
+// record[0] = value, record[1] = the 64-bit index (bit pattern), record[2 ..] = X[best] (xlen doubles).
+__global__ __launch_bounds__(1024) void k_best_record(int B, const double* __restrict__ value,
+                                                      const double* __restrict__ X, int xlen,
+                                                      long long base, double* __restrict__ record) {
+    __shared__ double sv[1024];
+    __shared__ int si[1024];
+    double bv = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        const double x = value[i];
+        if (x < bv) { bv = x; bi = i; }      // NaN never wins; strided scan keeps the lowest index per thread
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = sv[threadIdx.x + off];
+            const int oi = si[threadIdx.x + off];
+            if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int win = si[0];
+    const bool none = win == 0x7fffffff;                  // every value NaN or +inf (or B == 0)
+    if (threadIdx.x == 0) {
+        record[0] = none ? NAN : sv[0];
+        reinterpret_cast<long long*>(record)[1] = none ? -1 : base + win;
+    }
+    for (int e = threadIdx.x; e < xlen; e += 1024) record[2 + e] = none ? 0.0 : X[(size_t)win * xlen + e];
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
@@ -808,6 +842,14 @@ extern "C" int oei_argmin(int B, const double* value, long long index_base, doub
                           long long* best_index, void* stream) {
     if (B < 0 || !best_value || !best_index || (B > 0 && !value)) { oei_set_error("argmin: bad argument"); return OEI_ERR_ARG; }
     hipLaunchKernelGGL(k_argmin, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, value, index_base, best_value, best_index);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+extern "C" int oei_best_record(int B, const double* value, const double* X, int xlen, long long index_base,
+                               double* record, void* stream) {
+    if (B < 0 || xlen < 0 || !record || (B > 0 && (!value || (xlen > 0 && !X)))) { oei_set_error("best_record: bad argument"); return OEI_ERR_ARG; }
+    hipLaunchKernelGGL(k_best_record, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, value, X, xlen, index_base, record);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

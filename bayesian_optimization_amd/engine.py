@@ -246,3 +246,17 @@ def argmin(value, index_base=0):
         check(lib.oei_argmin(int(value.numel()), _ptr(value), int(index_base), _ptr(bv), _ptr(bi),
                              _stream()), 'oei_argmin')
     return bv, bi
+
+
+def best_record(value, X, index_base=0):
+    """Device arg-min (ties to the lowest index, NaN never wins) returning the winner's record
+    [value, index bits, X row ...] as one float64 tensor of 2 + X[0].numel() entries."""
+    value = value.contiguous()
+    X = X.contiguous()
+    B = int(value.numel())
+    xlen = int(X.numel() // B) if B else 0
+    rec = torch.empty(2 + xlen, dtype=torch.float64, device=value.device)
+    with torch.cuda.device(value.device):
+        check(lib.oei_best_record(B, _ptr(value), _ptr(X), xlen, int(index_base), _ptr(rec), _stream()),
+              'oei_best_record')
+    return rec

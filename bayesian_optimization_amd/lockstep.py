@@ -123,6 +123,109 @@ def minimize_lockstep(fun, X0, lower, upper, history=10, max_iter=200, pgtol=1e-
     return LockstepResult(x=x, fun=f, grad=g, nit=nit, nfev=nfev, converged=converged, message=message)
 
 
+def minimize_lockstep_newton(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-5, ftol=2.2e-9,
+                             c1=1e-4, max_ls=20):
+    """Projected Newton descent of every row of X0 [B, n] in lock-step: the batched consumer of
+    the exact Hessian (the role KNITRO's SQP plays in the reference, solvers.py:56-69, 71-141).
+    `fun(X[b, n]) -> (f[b], g[b, n])`, `hess(X[b, n]) -> H[b, n, n]` (a zero or non-finite matrix
+    is allowed: the step then falls back to a scaled gradient step).  Per iteration and run:
+      * variables blocked at a bound (lower with g > 0, upper with g < 0) are frozen;
+      * on the free variables (H + lam I) d = -g with the smallest lam from a geometric ladder
+        that makes the matrix positive definite (batched Cholesky; the acquisition is not
+        convex, so lam > 0 is the rule far from an optimum);
+      * projected backtracking line search x+ = P(x + t d) with the Armijo rule of
+        minimize_lockstep; same stopping rules (projected gradient, relative decrease).
+    Returns LockstepResult; `nfev` counts value+gradient calls, Hessian calls equal `nit` + 1 at most."""
+    x = torch.as_tensor(X0).clone()
+    B, n = x.shape
+    dev, dt = x.device, x.dtype
+    lo = torch.as_tensor(lower, dtype=dt, device=dev).expand(n).clone()
+    hi = torch.as_tensor(upper, dtype=dt, device=dev).expand(n).clone()
+    x = torch.minimum(torch.maximum(x, lo), hi)
+    f, g = fun(x)
+    f = f.clone()
+    g = g.clone().reshape(B, n)
+    nfev = torch.ones(B, dtype=torch.int64, device=dev)
+    nit = torch.zeros(B, dtype=torch.int64, device=dev)
+    bad0 = ~torch.isfinite(f)
+    done = bad0.clone()
+    converged = torch.zeros(B, dtype=torch.bool, device=dev)
+    eye = torch.eye(n, dtype=dt, device=dev)
+    for _ in range(max_iter):
+        pg = x - torch.minimum(torch.maximum(x - g, lo), hi)
+        hit = (pg.abs().amax(dim=1) <= pgtol) & ~done
+        converged |= hit
+        done |= hit
+        idx = torch.nonzero(~done).reshape(-1)
+        if idx.numel() == 0:
+            break
+        xa, ga, fa = x[idx], g[idx], f[idx]
+        H = hess(xa)
+        H = torch.where(torch.isfinite(H), H, torch.zeros_like(H))
+        H = 0.5 * (H + H.transpose(1, 2))
+        free = ~(((xa <= lo) & (ga > 0)) | ((xa >= hi) & (ga < 0)))
+        fm = free.to(dt)
+        Hm = H * fm[:, :, None] * fm[:, None, :] + torch.diag_embed(1.0 - fm)
+        scale = torch.clamp(Hm.abs().amax(dim=(1, 2)), min=1e-12)
+        lam = torch.zeros(idx.numel(), dtype=dt, device=dev)
+        L = None
+        for k in range(12):
+            Lk, info = torch.linalg.cholesky_ex(Hm + lam[:, None, None] * eye)
+            ok = info == 0
+            L = Lk if L is None else torch.where(ok[:, None, None] & (solved == 0)[:, None, None], Lk, L)
+            solved = ok.to(torch.int32) if k == 0 else torch.maximum(solved, ok.to(torch.int32))
+            if bool((solved == 1).all()):
+                break
+            lam = torch.where(solved == 1, lam, torch.where(lam > 0, 10.0 * lam, 1e-4 * scale))
+        unsolved = solved == 0
+        d = -torch.cholesky_solve((ga * fm)[:, :, None], torch.where(unsolved[:, None, None], eye.expand_as(L), L))[:, :, 0] * fm
+        gd = (ga * d).sum(dim=1)
+        resetv = ~(gd < 0) | unsolved
+        d = torch.where(resetv[:, None], -ga * fm, d)
+        dn = d.norm(dim=1)
+        # first trial: the Newton step, but no longer than the box diagonal
+        t = torch.clamp((hi - lo).norm() / torch.clamp(dn, min=1e-300), max=1.0)
+        stalled = ~(dn > 0)
+        x_new, f_new, g_new = xa.clone(), fa.clone(), ga.clone()
+        accepted = torch.zeros(idx.numel(), dtype=torch.bool, device=dev)
+        for _ls in range(max_ls):
+            sub = torch.nonzero(~accepted & ~stalled).reshape(-1)
+            if sub.numel() == 0:
+                break
+            xt = torch.minimum(torch.maximum(xa[sub] + t[sub, None] * d[sub], lo), hi)
+            ft, gt = fun(xt)
+            gt = gt.reshape(sub.numel(), n)
+            nfev[idx[sub]] += 1
+            ok = ft <= fa[sub] + c1 * (ga[sub] * (xt - xa[sub])).sum(dim=1)      # False for NaN / inf
+            oki = sub[ok]
+            x_new[oki], f_new[oki], g_new[oki] = xt[ok], ft[ok], gt[ok]
+            accepted[oki] = True
+            t[sub[~ok]] *= 0.25
+        small = accepted & ((fa - f_new) <= ftol * torch.maximum(torch.maximum(fa.abs(), f_new.abs()),
+                                                                  torch.ones_like(fa)))
+        converged[idx] |= small
+        done[idx] |= small | ~accepted
+        nit[idx] += accepted.to(torch.int64)
+        x[idx], f[idx], g[idx] = x_new, f_new, g_new
+    message = ['converged' if c else ('no finite start value' if b else 'stopped')
+               for c, b in zip(converged.tolist(), bad0.tolist())]
+    return LockstepResult(x=x, fun=f, grad=g, nit=nit, nfev=nfev, converged=converged, message=message)
+
+
+def acquisition_hess_fun(gp, q):
+    """Adapter from a DeviceGP to the `hess` of minimize_lockstep_newton: X [b, q*d] -> H [b, q*d, q*d]
+    through the batched acquisition_hessian (oei.py:41-64).  Candidates whose solve failed, and
+    candidates the reference's `project` would shrink (its Hessian is then zero, oei.py:53-55),
+    get a zero matrix."""
+    d = gp.dim
+
+    def hess(X):
+        b = X.shape[0]
+        H, status = gp.hessian(X.reshape(b, q, d))
+        return torch.where((status == 0)[:, None, None], H, torch.zeros_like(H))
+    return hess
+
+
 def acquisition_fun(gp, q, project_fallback=None, n_runs=None, warm_start=False, stats=None):
     """Adapter from a DeviceGP to the `fun` of minimize_lockstep: X [b, q*d] -> (value, grad).
     Candidates whose SDP did not solve get +inf (the line search then backs off).
@@ -167,7 +270,7 @@ def acquisition_fun(gp, q, project_fallback=None, n_runs=None, warm_start=False,
 
 
 def optimize_multistart(gp, X_starts, lower, upper, index_base=0, group=None, project_fallback=None,
-                        warm_start=False, stats=None, **kwargs):
+                        warm_start=False, stats=None, method='lbfgs', **kwargs):
     """Lock-step descent from the local shard of starts X_starts [B, q, d], then the global best
     over all ranks (one all-gather of a (value, index, X) record, see multistart.select_best).
     Returns (LockstepResult of the local shard, (best_value, best_index, best_X [q, d]))."""
@@ -178,8 +281,22 @@ def optimize_multistart(gp, X_starts, lower, upper, index_base=0, group=None, pr
     hi = torch.as_tensor(upper, dtype=torch.float64, device=gp.device)
     if lo.numel() == d:
         lo, hi = lo.repeat(q), hi.repeat(q)
-    res = minimize_lockstep(acquisition_fun(gp, q, project_fallback, n_runs=B, warm_start=warm_start, stats=stats),
-                            X0, lo, hi, **kwargs)
+    if method == 'newton':
+        # exact second-order steps on the batched Hessian, then the first-order method polishes
+        # the runs the Newton iteration left unconverged (it stops at the first rejected step)
+        fun = acquisition_fun(gp, q, project_fallback, stats=stats)
+        res = minimize_lockstep_newton(fun, acquisition_hess_fun(gp, q), X0, lo, hi,
+                                       **{k: v for k, v in kwargs.items() if k in ('max_iter', 'pgtol', 'ftol')})
+        todo = torch.nonzero(~res.converged & torch.isfinite(res.fun)).reshape(-1)
+        if todo.numel() > 0:
+            r2 = minimize_lockstep(fun, res.x[todo], lo, hi, **kwargs)
+            res.x[todo], res.fun[todo], res.grad[todo] = r2.x, r2.fun, r2.grad
+            res.nit[todo] += r2.nit
+            res.nfev[todo] += r2.nfev
+            res.converged[todo] = r2.converged
+    else:
+        res = minimize_lockstep(acquisition_fun(gp, q, project_fallback, n_runs=B, warm_start=warm_start, stats=stats),
+                                X0, lo, hi, **kwargs)
     fv = torch.where(torch.isfinite(res.fun), res.fun, torch.full_like(res.fun, float('nan')))
     bv, bi = engine.argmin(fv, index_base)
     local = torch.clamp(bi - index_base, min=0)

@@ -148,9 +148,12 @@ class BO(object):
         from .. import lockstep
         starts = np.stack([self.random_sample(self.bounds, batch_size)
                            for _ in range(self.options['opt_restarts'])])
+        # options['hessian'] (run.py --hessian, the flag that makes the reference hand exact
+        # Hessians to its SQP solver, solvers.py:56-69) selects the projected Newton iteration
         res, best = lockstep.optimize_multistart(
             self.device_model(), starts, self.bounds[:, 0], self.bounds[:, 1],
-            project_fallback=lambda x: (lambda r: (r[0][0], r[1]))(self.acquisition(x)))
+            project_fallback=lambda x: (lambda r: (r[0][0], r[1]))(self.acquisition(x)),
+            method='newton' if self.options.get('hessian') else 'lbfgs')
         log = logging.getLogger('opt')
         fun, nit = res.fun.cpu().numpy(), res.nit.cpu().numpy()
         for j in range(len(fun)):

@@ -59,9 +59,9 @@ def evaluate_and_select(gp, X_local, index_base=0, group=None):
     Returns (value [B], grad [B,q,d], status [B], (best_value, best_index, best_X [q,d]))."""
     from . import engine
     value, grad, status, _ = gp.value_grad(X_local, want_flags=False)
-    bv, bi = engine.argmin(value, index_base)
-    local = torch.clamp(bi - index_base, min=0)
-    Xb = X_local.reshape(X_local.shape[0], -1).index_select(0, local.reshape(1)).reshape(-1)
-    rec = make_record(bv, bi, Xb)
-    best_value, best_index, best_X = select_best(rec, group)
+    rec = engine.best_record(value, X_local, index_base)      # one launch: arg-min + record
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        best_value, best_index, best_X = select_best(rec, group)
+    else:                                                     # one rank: its record is the winner
+        best_value, best_index, best_X = rec[0], rec[1:2].view(torch.int64).reshape(()), rec[2:]
     return value, grad, status, (best_value, best_index, best_X.reshape(X_local.shape[1:]))

@@ -165,6 +165,12 @@ int oei_model_nlml(oei_model* m, double* value, double* grad, int n_lengthscales
 int oei_argmin(int B, const double* value, long long index_base,
                double* best_value, long long* best_index, void* stream);
 
+/* The same selection with the winner's whole record in one launch: record device double[2 + xlen]
+ * receives value, the 64-bit global index (bit pattern in record[1]; -1 if no finite value) and
+ * X[best] (xlen = q*d doubles) -- the unit of the cross-rank all-gather. */
+int oei_best_record(int B, const double* value, const double* X, int xlen, long long index_base,
+                    double* record, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

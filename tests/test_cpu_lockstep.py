@@ -4,6 +4,7 @@ import numpy as np
 import scipy.optimize
 import torch
 
+from bayesian_optimization_amd import lockstep
 from bayesian_optimization_amd.lockstep import minimize_lockstep
 
 
@@ -67,3 +68,29 @@ def test_rejects_non_finite_and_keeps_others():
     assert not res.converged[0] and res.message[0] == 'no finite start value'
     assert res.converged[1] and res.converged[2]
     assert torch.allclose(res.x[1:], torch.zeros(2, 2, dtype=torch.float64), atol=1e-5)
+
+
+def test_newton_lockstep_rosenbrock_active_bound():
+    """Projected Newton in lock-step (the batched consumer of exact Hessians): Rosenbrock with
+    the upper bound cutting off the unconstrained minimum; every run ends at (0.8, 0.64)."""
+    def hess(X):
+        x, y = X[:, 0], X[:, 1]
+        H = torch.zeros(X.shape[0], 2, 2, dtype=X.dtype)
+        H[:, 0, 0] = 2 - 400 * (y - x * x) + 800 * x * x
+        H[:, 0, 1] = H[:, 1, 0] = -400 * x
+        H[:, 1, 1] = 200
+        return H
+
+    def fun(X):
+        x, y = X[:, 0], X[:, 1]
+        f = (1 - x) ** 2 + 100 * (y - x * x) ** 2
+        return f, torch.stack([-2 * (1 - x) - 400 * x * (y - x * x), 200 * (y - x * x)], 1)
+    X0 = torch.tensor(np.random.RandomState(0).uniform(-1.5, 1.5, (16, 2)))
+    res = lockstep.minimize_lockstep_newton(fun, hess, X0, -2.0, 0.8)
+    assert bool(res.converged.all())
+    assert torch.allclose(res.x, torch.tensor([0.8, 0.64], dtype=torch.float64).expand(16, 2), atol=1e-6)
+    assert int(res.nfev.max()) <= 60
+    # a Hessian that is useless (zeros, NaN) degrades to gradient steps, never to a failure
+    res2 = lockstep.minimize_lockstep_newton(fun, lambda X: torch.full((X.shape[0], 2, 2), float('nan'), dtype=X.dtype),
+                                             X0[:4], -2.0, 0.8, max_iter=5)
+    assert bool((res2.fun <= fun(X0[:4])[0]).all())

@@ -200,3 +200,21 @@ def test_hessian_vs_oracle(cuda, n, q, kind, fm):
         scale = np.abs(Href).max()
         assert np.abs(H[b] - H[b].T).max() <= 1e-8 * scale
         assert np.abs(H[b] - Href).max() <= 1e-6 * scale, np.abs(H[b] - Href).max() / scale
+
+
+def test_best_record_ties_nan_and_empty(cuda):
+    """oei_best_record: the arg-min's winner with its X row in one launch; ties go to the lowest
+    index, NaN never wins, no finite value gives index -1."""
+    from bayesian_optimization_amd.engine import best_record
+    X = torch.arange(5 * 6, dtype=torch.float64, device=cuda).reshape(5, 2, 3)
+    v = torch.tensor([3.0, -1.0, float('nan'), -1.0, 0.5], dtype=torch.float64, device=cuda)
+    rec = best_record(v, X, index_base=100)
+    assert rec[0].item() == -1.0 and rec[1:2].view(torch.int64).item() == 101
+    assert torch.equal(rec[2:], X[1].reshape(-1))
+    rec = best_record(torch.full((4,), float('nan'), dtype=torch.float64, device=cuda), X[:4], index_base=7)
+    assert rec[1:2].view(torch.int64).item() == -1 and bool(torch.isnan(rec[0]))
+    big = torch.randn(5000, dtype=torch.float64, device=cuda)
+    Xb = torch.randn(5000, 4, dtype=torch.float64, device=cuda)
+    rec = best_record(big, Xb)
+    k = int(torch.argmin(big))
+    assert rec[1:2].view(torch.int64).item() == k and torch.equal(rec[2:], Xb[k])

@@ -34,3 +34,12 @@ for warm in (False, True):
     print('2048 starts lock-step, SDP warm start %s: %.2f s, %d evaluations in total, Newton iterations per evaluation %s, best %.6f, converged %d'
           % (warm, t_big, int(res.nfev.sum()), ('%.2f' % (st['newton'] / st['evals'])) if 'newton' in st else 'n/a (3.2 cold)',
              float(best[0]), int(res.converged.sum())))
+
+for method in ('lbfgs', 'newton'):
+    st = {}
+    sub = big[:512]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res, best = lockstep.optimize_multistart(gp, sub, [-.5] * 6, [.5] * 6, method=method, stats=st)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print('512 starts lock-step, method %s: %.2f s, %d value+gradient evaluations, best %.6f, mean %.6f, converged %d'
+          % (method, dt, st['evals'], float(best[0]), float(res.fun.mean()), int(res.converged.sum())))
