@@ -77,32 +77,48 @@ __device__ __forceinline__ void tile_mm(double acc[4][4], const double* __restri
     }
 }
 
-// ---- diagonal block: Cholesky of A_kk in LDS, plus its inverse ---------------------------------
-__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ Lm, int npad, int kb,
-                                               double* __restrict__ Dinv, int* __restrict__ flag) {
+// ---- diagonal block: Cholesky of A_kk and the inverse of its factor ------------------------------
+// One wave.  Lane i keeps row i of the block in registers; pivots and multipliers travel through
+// the scalar unit (v_readlane), so the 64 elimination steps need no barrier (a 256-thread version
+// with the block in LDS spent its time in 192 barriers: 165 us per block against about 40 us).
+// The inverse is built column by column from the factor in LDS: lane j, forward substitution.
+__device__ __forceinline__ double potf2_bcast(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void k_potf2(double* __restrict__ Lm, int npad, int kb,
+                                              double* __restrict__ Dinv, int* __restrict__ flag) {
     __shared__ double T[TB * TLD];
     __shared__ double Ti[TB * TLD];
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     double* Ablk = Lm + ((size_t)kb * TB) * npad + (size_t)kb * TB;
-    for (int e = tid; e < TB * TB; e += 256) T[(e / TB) * TLD + e % TB] = Ablk[(size_t)(e / TB) * npad + e % TB];
+    for (int e = lane; e < TB * TB; e += 64) T[(e / TB) * TLD + e % TB] = Ablk[(size_t)(e / TB) * npad + e % TB];
     __syncthreads();
+    double a[TB];
+#pragma unroll
+    for (int k = 0; k < TB; ++k) a[k] = (k <= lane) ? T[lane * TLD + k] : 0.0;
+    int bad = 0;
+#pragma unroll
     for (int k = 0; k < TB; ++k) {
-        double dkk = T[k * TLD + k];
-        if (!(dkk > 0.0)) { if (tid == 0) *flag = 1; dkk = 1.0; }
-        double piv = sqrt(dkk);
-        __syncthreads();
-        if (tid == 0) T[k * TLD + k] = piv;
-        for (int i = k + 1 + tid; i < TB; i += 256) T[i * TLD + k] /= piv;
-        __syncthreads();
-        for (int e = tid; e < (TB - k - 1) * (TB - k - 1); e += 256) {
-            int i = k + 1 + e / (TB - k - 1), j = k + 1 + e % (TB - k - 1);
-            if (j <= i) T[i * TLD + j] -= T[i * TLD + k] * T[j * TLD + k];
+        double dkk = potf2_bcast(a[k], k);
+        if (!(dkk > 0.0)) { bad = 1; dkk = 1.0; }              // identical in every lane
+        const double piv = sqrt(dkk);
+        const double lik = (lane > k) ? a[k] / piv : (lane == k ? piv : 0.0);
+        a[k] = lik;
+#pragma unroll
+        for (int jj = k + 1; jj < TB; ++jj) {
+            const double ljk = potf2_bcast(lik, jj);           // L[jj][k]
+            if (lane >= jj) a[jj] -= lik * ljk;
         }
-        __syncthreads();
     }
-    // inverse of the lower-triangular block: thread j builds column j by forward substitution
-    if (tid < TB) {
-        const int j = tid;
+    if (bad && lane == 0) *flag = 1;
+#pragma unroll
+    for (int k = 0; k < TB; ++k) T[lane * TLD + k] = a[k];     // zeros above the diagonal
+    __syncthreads();
+    {   // inverse of the lower-triangular block: lane j builds column j by forward substitution
+        const int j = lane;
         for (int i = 0; i < TB; ++i) {
             double s = (i == j) ? 1.0 : 0.0;
             for (int k = j; k < i; ++k) s -= T[i * TLD + k] * Ti[k * TLD + j];
@@ -110,9 +126,9 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ Lm, int npad
         }
     }
     __syncthreads();
-    for (int e = tid; e < TB * TB; e += 256) {
+    for (int e = lane; e < TB * TB; e += 64) {
         int r = e / TB, c = e % TB;
-        Ablk[(size_t)r * npad + c] = (c <= r) ? T[r * TLD + c] : 0.0;
+        Ablk[(size_t)r * npad + c] = T[r * TLD + c];
         Dinv[(size_t)kb * TB * TB + e] = Ti[r * TLD + c];
     }
 }
@@ -215,26 +231,34 @@ __global__ void k_matvec(const double* __restrict__ Mat, const double* __restric
     if (threadIdx.x == 0) out[i] = s;
 }
 
-// mean_i = sum_j k(X_i, X_j) alpha_j for i < n  -> global minimum (single block)
-__global__ __launch_bounds__(256) void k_fmin(KernParams kp, const double* __restrict__ X, int n,
-                                              const double* __restrict__ alpha,
+// mean_i = sum_j k(X_i, X_j) alpha_j for i < n (one workgroup per training point), then the minimum
+__global__ __launch_bounds__(256) void k_train_mean(KernParams kp, const double* __restrict__ X, int n,
+                                                    const double* __restrict__ alpha,
+                                                    double* __restrict__ mean) {
+    __shared__ double red[4];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double t = 0.0;
+        for (int l = 0; l < kp.d; ++l) {
+            double df = X[(size_t)i * kp.d + l] - X[(size_t)j * kp.d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        s += kp.variance * k0 * alpha[j];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) mean[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_fmin(const double* __restrict__ mean, int n,
                                               double* __restrict__ fmin_out) {
     __shared__ double red[4];
     double best = INFINITY;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) {
-            double t = 0.0;
-            for (int l = 0; l < kp.d; ++l) {
-                double df = X[(size_t)i * kp.d + l] - X[(size_t)j * kp.d + l];
-                t += df * df * kp.inv_ls2[l];
-            }
-            double k0, k1, k2;
-            kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
-            s += kp.variance * k0 * alpha[j];
-        }
-        best = fmin(best, s);
-    }
+    for (int i = threadIdx.x; i < n; i += 256) best = fmin(best, mean[i]);
     best = wave_min(best);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
     __syncthreads();
@@ -305,7 +329,7 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
         hipLaunchKernelGGL(k_gram_train, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->kp, m->X, n, npad, noise, m->L);
         const int nb = npad / TB;
         for (int kb = 0; kb < nb; ++kb) {
-            hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), 0, st, m->L, npad, kb, Dinv, dflag);
+            hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, m->L, npad, kb, Dinv, dflag);
             const int rem = nb - kb - 1;
             if (rem > 0) {
                 hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), 0, st, m->L, npad, kb, Dinv);
@@ -317,7 +341,9 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
         hipLaunchKernelGGL(k_transpose, dim3(npad / 32, npad / 32), dim3(32, 32), 0, st, m->Linv, m->LinvT, npad);
         hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->Linv, m->y, m->v, npad);
         hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->LinvT, m->v, m->alpha, npad);
-        hipLaunchKernelGGL(k_fmin, dim3(1), dim3(256), 0, st, m->kp, m->X, n, m->alpha, dfmin);
+        // tmp (npad * 64 doubles) is free again after the triangular inverse: n posterior means go there
+        hipLaunchKernelGGL(k_train_mean, dim3(n), dim3(256), 0, st, m->kp, m->X, n, m->alpha, tmp);
+        hipLaunchKernelGGL(k_fmin, dim3(1), dim3(256), 0, st, tmp, n, dfmin);
         OEI_HIP_CHECK(hipGetLastError());
         OEI_HIP_CHECK(hipDeviceSynchronize());
         int flag = 0;

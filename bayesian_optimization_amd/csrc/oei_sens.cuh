@@ -379,25 +379,31 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         w.step[tid] = sv.dmu[tid] + acc;
     }
     __syncthreads();
-    for (int k = 0; k < q; ++k) {                              // L y = rhs
-        const double yk = w.step[k] * w.rc[k];
-        __syncthreads();
-        if (tid == k) w.step[k] = yk;
-        if (tid > k && tid < q) w.step[tid] -= w.H[tid * LD + k] * yk;
-        __syncthreads();
-    }
-    for (int k = q - 1; k >= 0; --k) {                         // L^T x = y
-        const double xk = w.step[k] * w.rc[k];
-        __syncthreads();
-        if (tid == k) w.step[k] = xk;
-        if (tid < k) w.step[tid] -= w.H[k * LD + tid] * xk;
-        __syncthreads();
-    }
-    if (tid < q) {
-        const double dp = -w.step[tid], ipi = w.ip[tid];
-        sv.dp[tid] = dp;
-        scl[tid] = dp * ipi * ipi;
-        wv[tid] = dp * ipi;                                    // wv is free again
+    // (-hess g) x = rhs with the factor L in w.H: the first wave alone, one row per lane, the
+    // running vector in a register and every solved component broadcast through the scalar unit
+    // (a workgroup-wide substitution costs two barriers per component: half of a direction's time)
+    if (tid < 64) {
+        const int row = tid < q ? tid : 0;
+        const double dinv = w.rc[row];
+        double bv = (tid < q) ? w.step[row] : 0.0;
+#pragma unroll 4
+        for (int k = 0; k < q; ++k) {                          // L y = rhs
+            const double lk = w.H[row * LD + k];
+            const double yk = sdp_lane_bcast(bv * dinv, k);
+            bv = (tid == k) ? yk : (tid > k ? bv - lk * yk : bv);
+        }
+#pragma unroll 4
+        for (int k = q - 1; k >= 0; --k) {                     // L^T x = y
+            const double lk = w.H[k * LD + row];
+            const double xk = sdp_lane_bcast(bv * dinv, k);
+            bv = (tid == k) ? xk : (tid < k ? bv - lk * xk : bv);
+        }
+        if (tid < q) {
+            const double dp = -bv, ipi = w.ip[tid];
+            sv.dp[tid] = dp;
+            scl[tid] = dp * ipi * ipi;
+            wv[tid] = dp * ipi;                                // wv is free again
+        }
     }
     __syncthreads();
     double sdp = 0.0;

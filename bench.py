@@ -62,6 +62,26 @@ def flops_model(q, n, npad, newton_iters, sweeps):
     return moments + zmat + factor + evals * per_eval + sweeps * per_sweep + newton_iters * per_dir
 
 
+def hessian_flops_model(q, d, n, npad, sdp_flops):
+    """Algorithmic flops of one acquisition Hessian (fma = 2 flops), q <= 32 path:
+      front     RP = q(d+1)+1 rows (values, d derivative components, y; padded to 64) through the
+                triangular GEMM with L^-1 (K range of a 64-column tile stops at its diagonal), then
+                the Gram matrix of the block (lower block triangle, n-length sums)
+      solve     the SDP solve of the value+gradient path (`sdp_flops`) plus W = Z L^-1
+      dirs      q d directions: four q^3 products, about 12 q^2 for the vector passes and the two
+                triangular solves, and the contraction of the direction's row with every
+                dOmega_(b,m): q d (2 q + 30)
+    """
+    RP = -(-(q * (d + 1) + 1) // 64) * 64
+    nt = npad // 64
+    tri = 64 * 64 * nt * (nt + 1)                      # per row: column tile j takes 64 * 64 (j + 1) multiply-adds
+    front = RP * tri + (RP // 64) * (RP // 64 + 1) // 2 * 2 * 64 * 64 * npad
+    solve = sdp_flops + q * tri
+    qd = q * d
+    dirs = qd * (8 * q ** 3 + 12 * q * q) + qd * qd * (2 * q + 30)
+    return front + solve + dirs
+
+
 def candidate_block(total, q, d, seed, lo, hi, chunk=4096):
     """Rows [lo, hi) of the global candidate array RandomState(seed).uniform(-.5, .5, (total, q, d)),
     drawn chunk by chunk so that a rank never holds more than its block plus one chunk."""
@@ -261,8 +281,14 @@ def main():
                     _, hst = gp.hessian(X_local[:hb])
                 torch.cuda.synchronize()
                 th = (time.perf_counter() - th) / 3
+                hfl = hessian_flops_model(q, d, n, gp.n + (-gp.n) % 64, fl / B)
                 hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
-                           'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item())}
+                           'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item()),
+                           'roofline': {'bound': 'fp64 (MFMA front end, vector-unit directions)',
+                                        'flops_per_hessian': hfl, 'achieved': hfl * hb / th / 1e12,
+                                        'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                        'frac': hfl * hb / th / 1e12 / FP64_PEAK_TFLOPS,
+                                        'note': 'whole call (8 launches), wall clock over 3 calls'}}
             if not args.no_cpu_baseline and world == 1:
                 # the CPU restatement of the reference path (oracle) timed on this box's host
                 # cores, on a bounded sample of the benchmark's own candidates

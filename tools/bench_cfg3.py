@@ -1,7 +1,8 @@
 """Diagnostic: value+gradient throughput at the largest configuration (n=1000, q=50, d=10)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import hart6, gp as ogp
 from bayesian_optimization_amd import DeviceGP
 
