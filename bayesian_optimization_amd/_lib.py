@@ -22,6 +22,7 @@ SIGNATURES = {
                                         ctypes.c_int, ctypes.c_int, ctypes.c_double, vp,
                                         ctypes.c_int, ctypes.c_double]),
     'oei_model_destroy': (ctypes.c_int, [vp]),
+    'oei_model_refactor': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, vp, ctypes.c_int, ctypes.c_double]),
     'oei_model_info': (ctypes.c_int, [vp, c_double_p, c_int_p, c_int_p]),
     'oei_model_get_factor': (ctypes.c_int, [vp, vp]),
     'oei_predict_f': (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp]),

@@ -55,6 +55,13 @@ struct oei_model {
     double* aux;      // per-candidate state (p, M11, ...)
     size_t hs_bytes;  // Hessian-path scratch (Gram blocks, Z/W rows)
     double* hs;
+    // factorisation temporaries, kept so that oei_model_refactor allocates nothing
+    double* Dinv;     // [npad, 64] inverses of the diagonal blocks
+    double* ftmp;     // [npad, 64] per-column-block tile of the triangular inverse; training means
+    double* dscal;    // [2] fmin | nlml value
+    int* dflag;       // not-positive-definite flag
+    double* Kinv;     // [npad, npad] K^-1 (hyper-parameter gradient), allocated on first use
+    double* nlml_part;   // [n, 2 + d] per-row gradient terms, allocated on first use
     int profile;      // record stage events in value_grad
     hipEvent_t ev[6];
     int ev_valid;

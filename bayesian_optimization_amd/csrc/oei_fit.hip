@@ -68,23 +68,20 @@ extern "C" int oei_model_nlml(oei_model* m, double* value, double* grad, int n_l
     }
     const int n = m->n, npad = m->npad, nq = 2 + nls;
     hipStream_t st = 0;
-    double* dval = nullptr;
-    OEI_HIP_CHECK(hipMalloc(&dval, sizeof(double)));
+    double* dval = m->dscal + 1;
     hipLaunchKernelGGL(k_nlml_value, dim3(1), dim3(256), 0, st, m->L, m->y, m->alpha, n, npad, dval);
     int rc = OEI_OK;
-    double* Kinv = nullptr;
-    double* partial = nullptr;
     if (grad) {
-        if (hipMalloc(&Kinv, (size_t)npad * npad * sizeof(double)) != hipSuccess ||
-            hipMalloc(&partial, (size_t)n * nq * sizeof(double)) != hipSuccess) {
-            hipFree(dval); hipFree(Kinv); hipFree(partial);
-            oei_set_error("model_nlml: out of device memory");
-            return OEI_ERR_HIP;
-        }
-        rc = oei_launch_gemm_nt(m->LinvT, m->LinvT, Kinv, (size_t)npad, npad, 0, st);   // L^-T L^-1
+        // K^-1 and the per-row terms live in the handle (allocated once: an optimiser calls this
+        // hundreds of times on one handle, see oei_model_refactor)
+        if (!m->Kinv && hipMalloc(&m->Kinv, (size_t)npad * npad * sizeof(double)) != hipSuccess) { m->Kinv = nullptr; oei_set_error("model_nlml: out of device memory"); return OEI_ERR_HIP; }
+        if (!m->nlml_part && hipMalloc(&m->nlml_part, (size_t)n * (2 + m->d) * sizeof(double)) != hipSuccess) { m->nlml_part = nullptr; oei_set_error("model_nlml: out of device memory"); return OEI_ERR_HIP; }
+        rc = oei_launch_gemm_nt(m->LinvT, m->LinvT, m->Kinv, (size_t)npad, npad, 0, st);   // L^-T L^-1
         if (rc == OEI_OK)
-            hipLaunchKernelGGL(k_nlml_grad, dim3(n), dim3(256), 0, st, m->kp, m->X, Kinv, m->alpha, n, npad, nls, partial);
+            hipLaunchKernelGGL(k_nlml_grad, dim3(n), dim3(256), 0, st, m->kp, m->X, m->Kinv, m->alpha, n, npad, nls, m->nlml_part);
     }
+    double* Kinv = m->Kinv;
+    double* partial = m->nlml_part;
     if (rc == OEI_OK && hipGetLastError() != hipSuccess) { oei_set_error("model_nlml: launch failed"); rc = OEI_ERR_HIP; }
     if (rc == OEI_OK && hipMemcpy(value, dval, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { oei_set_error("model_nlml: copy failed"); rc = OEI_ERR_HIP; }
     if (rc == OEI_OK && grad) {
@@ -100,6 +97,6 @@ extern "C" int oei_model_nlml(oei_model* m, double* value, double* grad, int n_l
         }
         delete[] host;
     }
-    hipFree(dval); hipFree(Kinv); hipFree(partial);
+    (void)Kinv;
     return rc;
 }

@@ -271,8 +271,61 @@ static void model_free(oei_model* m) {
     hipFree(m->X); hipFree(m->L); hipFree(m->Linv); hipFree(m->LinvT);
     hipFree(m->v); hipFree(m->alpha); hipFree(m->y);
     hipFree(m->ws0); hipFree(m->ws1); hipFree(m->ws2); hipFree(m->aux); hipFree(m->hs);
+    hipFree(m->Dinv); hipFree(m->ftmp); hipFree(m->dscal); hipFree(m->dflag); hipFree(m->Kinv); hipFree(m->nlml_part);
     if (m->ev[0]) for (int i = 0; i < 6; ++i) hipEventDestroy(m->ev[i]);
     delete m;
+}
+
+static int set_hyper(oei_model* m, int kernel_kind, int floor_mode, double variance,
+                     const double* lengthscales, int n_lengthscales, double noise, const char* who) {
+    const int d = m->d;
+    if (kernel_kind != OEI_KERNEL_RBF && kernel_kind != OEI_KERNEL_MATERN32) { oei_set_error("%s: unknown kernel %d", who, kernel_kind); return OEI_ERR_ARG; }
+    if (floor_mode < 0 || floor_mode > 2) { oei_set_error("%s: unknown floor mode %d", who, floor_mode); return OEI_ERR_ARG; }
+    if (!lengthscales || (n_lengthscales != 1 && n_lengthscales != d)) { oei_set_error("%s: need 1 or d lengthscales", who); return OEI_ERR_ARG; }
+    if (!(variance > 0.0) || !(noise >= 0.0)) { oei_set_error("%s: variance/noise out of range", who); return OEI_ERR_ARG; }
+    for (int l = 0; l < d; ++l)
+        if (!(lengthscales[n_lengthscales == 1 ? 0 : l] > 0.0)) { oei_set_error("%s: lengthscale <= 0", who); return OEI_ERR_ARG; }
+    m->noise = noise;
+    m->kp.kind = kernel_kind; m->kp.floor_mode = floor_mode; m->kp.d = d; m->kp.variance = variance;
+    for (int l = 0; l < d; ++l) {
+        const double ls = lengthscales[n_lengthscales == 1 ? 0 : l];
+        m->kp.inv_ls[l] = 1.0 / ls;
+        m->kp.ls[l] = ls;
+        m->kp.inv_ls2[l] = 1.0 / (ls * ls);
+    }
+    return OEI_OK;
+}
+
+// K + noise I -> L, L^-1, L^-T, v, alpha, fmin from the data and hyper-parameters in the handle.
+// Allocates nothing; synchronous.
+static int factorise(oei_model* m) {
+    const int n = m->n, npad = m->npad;
+    hipStream_t st = 0;
+    OEI_HIP_CHECK(hipMemsetAsync(m->dflag, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_gram_train, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->kp, m->X, n, npad, m->noise, m->L);
+    const int nb = npad / TB;
+    for (int kb = 0; kb < nb; ++kb) {
+        hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, m->L, npad, kb, m->Dinv, m->dflag);
+        const int rem = nb - kb - 1;
+        if (rem > 0) {
+            hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), 0, st, m->L, npad, kb, m->Dinv);
+            hipLaunchKernelGGL(k_syrk_trail, dim3(rem, rem), dim3(256), 0, st, m->L, npad, kb);
+        }
+    }
+    hipLaunchKernelGGL(k_zero_upper, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->L, npad);
+    hipLaunchKernelGGL(k_trinv, dim3(nb), dim3(256), 0, st, m->L, npad, m->Dinv, m->Linv, m->ftmp);
+    hipLaunchKernelGGL(k_transpose, dim3(npad / 32, npad / 32), dim3(32, 32), 0, st, m->Linv, m->LinvT, npad);
+    hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->Linv, m->y, m->v, npad);
+    hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->LinvT, m->v, m->alpha, npad);
+    // ftmp is free again after the triangular inverse: the n posterior means go there
+    hipLaunchKernelGGL(k_train_mean, dim3(n), dim3(256), 0, st, m->kp, m->X, n, m->alpha, m->ftmp);
+    hipLaunchKernelGGL(k_fmin, dim3(1), dim3(256), 0, st, m->ftmp, n, m->dscal);
+    OEI_HIP_CHECK(hipGetLastError());
+    int flag = 0;
+    OEI_HIP_CHECK(hipMemcpy(&flag, m->dflag, sizeof(int), hipMemcpyDeviceToHost));      // waits for the stream
+    OEI_HIP_CHECK(hipMemcpy(&m->fmin, m->dscal, sizeof(double), hipMemcpyDeviceToHost));
+    if (flag) { oei_set_error("K + noise*I is not positive definite"); return OEI_ERR_NOT_PD; }
+    return OEI_OK;
 }
 
 extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_train,
@@ -280,34 +333,30 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
                                 const double* lengthscales, int n_lengthscales, double noise) {
     if (!out || !X_train || !y || !lengthscales) { oei_set_error("model_create: null pointer"); return OEI_ERR_ARG; }
     if (n < 1 || d < 1 || d > OEI_MAX_DIM) { oei_set_error("model_create: n=%d d=%d out of range (d <= %d)", n, d, OEI_MAX_DIM); return OEI_ERR_ARG; }
-    if (kernel_kind != OEI_KERNEL_RBF && kernel_kind != OEI_KERNEL_MATERN32) { oei_set_error("model_create: unknown kernel %d", kernel_kind); return OEI_ERR_ARG; }
-    if (floor_mode < 0 || floor_mode > 2) { oei_set_error("model_create: unknown floor mode %d", floor_mode); return OEI_ERR_ARG; }
-    if (n_lengthscales != 1 && n_lengthscales != d) { oei_set_error("model_create: need 1 or d lengthscales"); return OEI_ERR_ARG; }
-    if (!(variance > 0.0) || !(noise >= 0.0)) { oei_set_error("model_create: variance/noise out of range"); return OEI_ERR_ARG; }
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { oei_set_error("no HIP device"); return OEI_ERR_NO_DEVICE; }
-
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        // argument errors are reported even without a device
+        oei_model probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.d = d;
+        const int prc = set_hyper(&probe, kernel_kind, floor_mode, variance, lengthscales, n_lengthscales, noise, "model_create");
+        if (prc) return prc;
+        oei_set_error("no HIP device");
+        return OEI_ERR_NO_DEVICE;
+    }
     oei_model* m = new oei_model();
     memset(m, 0, sizeof(*m));
+    m->n = n; m->d = d;
+    m->npad = ((n + OEI_NPAD - 1) / OEI_NPAD) * OEI_NPAD;
+    int rc = set_hyper(m, kernel_kind, floor_mode, variance, lengthscales, n_lengthscales, noise, "model_create");
+    if (rc) { delete m; return rc; }
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; oei_set_error("model_create: hipGetDevice failed"); return OEI_ERR_HIP; }
     if (m->device < 64) {       // set-up of the allocation-free entry point for this device
         const int src = oei_noalloc_setup_device(m->device);
         if (src != OEI_OK) { delete m; return src; }
     }
-    m->n = n; m->d = d; m->noise = noise;
-    m->npad = ((n + OEI_NPAD - 1) / OEI_NPAD) * OEI_NPAD;
-    m->kp.kind = kernel_kind; m->kp.floor_mode = floor_mode; m->kp.d = d; m->kp.variance = variance;
-    for (int l = 0; l < d; ++l) {
-        double ls = lengthscales[n_lengthscales == 1 ? 0 : l];
-        if (!(ls > 0.0)) { delete m; oei_set_error("model_create: lengthscale <= 0"); return OEI_ERR_ARG; }
-        m->kp.inv_ls[l] = 1.0 / ls;
-        m->kp.ls[l] = ls;
-        m->kp.inv_ls2[l] = 1.0 / (ls * ls);
-    }
     const int npad = m->npad;
     const size_t nn = (size_t)npad * npad * sizeof(double);
-    double *Dinv = nullptr, *tmp = nullptr, *dfmin = nullptr; int* dflag = nullptr;
-    int rc = OEI_OK;
     auto body = [&]() -> int {
         OEI_HIP_CHECK(hipMalloc(&m->X, (size_t)npad * d * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&m->L, nn));
@@ -316,47 +365,33 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
         OEI_HIP_CHECK(hipMalloc(&m->v, npad * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&m->alpha, npad * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&m->y, npad * sizeof(double)));
-        OEI_HIP_CHECK(hipMalloc(&Dinv, (size_t)npad * TB * sizeof(double)));
-        OEI_HIP_CHECK(hipMalloc(&tmp, (size_t)npad * TB * sizeof(double)));
-        OEI_HIP_CHECK(hipMalloc(&dfmin, sizeof(double)));
-        OEI_HIP_CHECK(hipMalloc(&dflag, sizeof(int)));
+        OEI_HIP_CHECK(hipMalloc(&m->Dinv, (size_t)npad * TB * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->ftmp, (size_t)npad * TB * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->dscal, 2 * sizeof(double)));
+        OEI_HIP_CHECK(hipMalloc(&m->dflag, sizeof(int)));
         OEI_HIP_CHECK(hipMemset(m->X, 0, (size_t)npad * d * sizeof(double)));
         OEI_HIP_CHECK(hipMemset(m->y, 0, npad * sizeof(double)));
-        OEI_HIP_CHECK(hipMemset(dflag, 0, sizeof(int)));
         OEI_HIP_CHECK(hipMemcpy(m->X, X_train, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice));
         OEI_HIP_CHECK(hipMemcpy(m->y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-        hipStream_t st = 0;
-        hipLaunchKernelGGL(k_gram_train, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->kp, m->X, n, npad, noise, m->L);
-        const int nb = npad / TB;
-        for (int kb = 0; kb < nb; ++kb) {
-            hipLaunchKernelGGL(k_potf2, dim3(1), dim3(64), 0, st, m->L, npad, kb, Dinv, dflag);
-            const int rem = nb - kb - 1;
-            if (rem > 0) {
-                hipLaunchKernelGGL(k_trsm_panel, dim3(rem), dim3(256), 0, st, m->L, npad, kb, Dinv);
-                hipLaunchKernelGGL(k_syrk_trail, dim3(rem, rem), dim3(256), 0, st, m->L, npad, kb);
-            }
-        }
-        hipLaunchKernelGGL(k_zero_upper, dim3((npad + 255) / 256, npad), dim3(256), 0, st, m->L, npad);
-        hipLaunchKernelGGL(k_trinv, dim3(nb), dim3(256), 0, st, m->L, npad, Dinv, m->Linv, tmp);
-        hipLaunchKernelGGL(k_transpose, dim3(npad / 32, npad / 32), dim3(32, 32), 0, st, m->Linv, m->LinvT, npad);
-        hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->Linv, m->y, m->v, npad);
-        hipLaunchKernelGGL(k_matvec, dim3(npad), dim3(64), 0, st, m->LinvT, m->v, m->alpha, npad);
-        // tmp (npad * 64 doubles) is free again after the triangular inverse: n posterior means go there
-        hipLaunchKernelGGL(k_train_mean, dim3(n), dim3(256), 0, st, m->kp, m->X, n, m->alpha, tmp);
-        hipLaunchKernelGGL(k_fmin, dim3(1), dim3(256), 0, st, tmp, n, dfmin);
-        OEI_HIP_CHECK(hipGetLastError());
-        OEI_HIP_CHECK(hipDeviceSynchronize());
-        int flag = 0;
-        OEI_HIP_CHECK(hipMemcpy(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost));
-        OEI_HIP_CHECK(hipMemcpy(&m->fmin, dfmin, sizeof(double), hipMemcpyDeviceToHost));
-        if (flag) { oei_set_error("model_create: K + noise*I is not positive definite"); return OEI_ERR_NOT_PD; }
-        return OEI_OK;
+        return factorise(m);
     };
     rc = body();
-    hipFree(Dinv); hipFree(tmp); hipFree(dfmin); hipFree(dflag);
     if (rc != OEI_OK) { model_free(m); return rc; }
     *out = m;
     return OEI_OK;
+}
+
+extern "C" int oei_model_refactor(oei_model* m, int kernel_kind, int floor_mode, double variance,
+                                  const double* lengthscales, int n_lengthscales, double noise) {
+    if (!m) { oei_set_error("model_refactor: null model"); return OEI_ERR_ARG; }
+    int rc = set_hyper(m, kernel_kind, floor_mode, variance, lengthscales, n_lengthscales, noise, "model_refactor");
+    if (rc) return rc;
+    int cur = -1;
+    OEI_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != m->device) OEI_HIP_CHECK(hipSetDevice(m->device));
+    rc = factorise(m);
+    if (cur != m->device) hipSetDevice(cur);
+    return rc;
 }
 
 extern "C" int oei_model_destroy(oei_model* m) {

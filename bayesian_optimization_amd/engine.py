@@ -64,6 +64,20 @@ class DeviceGP:
         check(lib.oei_model_info(self._h, ctypes.byref(fmin), None, None), 'oei_model_info')
         self.fmin = fmin.value
 
+    def refactor(self, variance, lengthscales, noise):
+        """New hyper-parameters on the same data, in the handle's buffers (no device allocation):
+        one trial point of the hyper-parameter fit (bo.py:194-221).  Raises OeiError when the
+        covariance is not positive definite; the handle can then be refactored again."""
+        ls = np.ascontiguousarray(np.atleast_1d(np.asarray(lengthscales, dtype=np.float64)))
+        with torch.cuda.device(self.device):
+            check(lib.oei_model_refactor(self._h, self.kernel_kind, self.floor_mode, float(variance),
+                                         ls.ctypes.data_as(ctypes.c_void_p), int(ls.size), float(noise)),
+                  'oei_model_refactor')
+        self.variance, self.lengthscales, self.noise = float(variance), ls, float(noise)
+        fmin = ctypes.c_double(0.0)
+        check(lib.oei_model_info(self._h, ctypes.byref(fmin), None, None), 'oei_model_info')
+        self.fmin = fmin.value
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h.value:
             lib.oei_model_destroy(self._h)          # leaves the caller's current device as it was

@@ -29,22 +29,31 @@ def _neg_log_prior(variance, ls, priors):
     return val, dvar, dls
 
 
-def objective(theta, X, y, kind, floor_mode, ard, fixed_noise, priors, device=None):
+def objective(theta, X, y, kind, floor_mode, ard, fixed_noise, priors, device=None, gp=None):
     """theta = log([variance, lengthscale(s), noise]) (noise absent when fixed).  Returns
-    (value, gradient with respect to theta); +inf when the covariance is not positive definite."""
+    (value, gradient with respect to theta); +inf when the covariance is not positive definite.
+    `gp`: a one-element list holding the DeviceGP to re-factorise in place (created on first use);
+    without it a model is built and released for this one evaluation."""
     d = X.shape[1]
     nls = d if ard else 1
     variance = float(np.exp(theta[0]))
     ls = np.exp(theta[1:1 + nls])
     noise = float(fixed_noise) if fixed_noise is not None else float(np.exp(theta[1 + nls]))
     try:
-        gp = DeviceGP(X, y, kind, variance, ls, noise, floor_mode=floor_mode, device=device)
+        if gp is None:
+            model = DeviceGP(X, y, kind, variance, ls, noise, floor_mode=floor_mode, device=device)
+        elif gp[0] is None:
+            model = gp[0] = DeviceGP(X, y, kind, variance, ls, noise, floor_mode=floor_mode, device=device)
+        else:
+            model = gp[0]
+            model.refactor(variance, ls, noise)
     except _lib.OeiError:
         return np.inf, np.zeros_like(theta)
     try:
-        value, grad = gp.nlml(want_grad=True, ard=ard)
+        value, grad = model.nlml(want_grad=True, ard=ard)
     finally:
-        gp.close()
+        if gp is None:
+            model.close()
     pv, dvar, dls = _neg_log_prior(variance, ls, priors)
     value += pv
     g = np.empty_like(theta)
@@ -70,21 +79,27 @@ def fit(X, y, kind, variance, lengthscales, noise, floor_mode=None, ard=False, f
     fn = float(noise) if fixed_noise else None
     theta0 = np.log(np.concatenate([[variance], ls0] + ([] if fixed_noise else [[max(noise, 1e-12)]])))
 
+    holder = [None]         # one device model for the whole fit, re-factorised per trial point
+
     def f(th):
-        return objective(th, X, y, kind, floor_mode, ard, fn, priors, device)
-    best_theta, best_val = theta0, f(theta0)[0]
-    for _ in range(int(restarts)):
-        start = rng.randn(theta0.size)
-        try:
-            res = scipy.optimize.minimize(f, start, jac=True, method='L-BFGS-B',
-                                          bounds=[(-12.0, 8.0)] * theta0.size, options={'maxiter': maxiter})
-            val, th = float(res.fun), res.x
-        except KeyboardInterrupt:
-            raise
-        except Exception:
-            val, th = np.inf, start
-        if val < best_val:
-            best_theta, best_val = th, val
+        return objective(th, X, y, kind, floor_mode, ard, fn, priors, device, gp=holder)
+    try:
+        best_theta, best_val = theta0, f(theta0)[0]
+        for _ in range(int(restarts)):
+            start = rng.randn(theta0.size)
+            try:
+                res = scipy.optimize.minimize(f, start, jac=True, method='L-BFGS-B',
+                                              bounds=[(-12.0, 8.0)] * theta0.size, options={'maxiter': maxiter})
+                val, th = float(res.fun), res.x
+            except KeyboardInterrupt:
+                raise
+            except Exception:
+                val, th = np.inf, start
+            if val < best_val:
+                best_theta, best_val = th, val
+    finally:
+        if holder[0] is not None:
+            holder[0].close()
     out_noise = float(noise) if fixed_noise else float(np.exp(best_theta[1 + nls]))
     return dict(variance=float(np.exp(best_theta[0])), lengthscales=np.exp(best_theta[1:1 + nls]),
                 noise=out_noise, nlml=float(best_val))

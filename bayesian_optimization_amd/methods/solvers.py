@@ -26,8 +26,16 @@ def bfgs_solve(x_init, bounds, hessian, bo):
 
 def newton_solve(x_init, bounds, hessian, bo):
     """Bounded second-order solve using the exact acquisition Hessian (role of solvers.py:71-141)."""
-    fun = lambda x: float(bo.acquisition(x)[0][0])
-    jac = lambda x: bo.acquisition(x)[1]
+    last = {}           # value and gradient of one iterate come from one device evaluation
+
+    def both(x):
+        if last.get('x') is None or not np.array_equal(last['x'], x):
+            value, grad = bo.acquisition(x)
+            last['x'], last['value'], last['grad'] = np.array(x, copy=True), float(value[0]), grad
+        return last
+
+    fun = lambda x: both(x)['value']
+    jac = lambda x: both(x)['grad']
     hess = (lambda x: bo.acquisition_hessian(x)) if hessian else scipy.optimize.SR1()
     res = scipy.optimize.minimize(fun, x_init, method='trust-constr', jac=jac, hess=hess,
                                   bounds=scipy.optimize.Bounds(bounds[:, 0], bounds[:, 1]),

@@ -67,6 +67,13 @@ int oei_model_create(oei_model** out, int n, int d,
                      int kernel_kind, int floor_mode, double variance,
                      const double* lengthscales, int n_lengthscales, double noise);
 int oei_model_destroy(oei_model* m);
+/* Same data, new hyper-parameters: recomputes K, its factor, L^-1, L^-1 y and fmin in the handle's
+ * existing buffers (no device allocation or release).  This is one objective evaluation of the
+ * hyper-parameter fit (bo.py:194-221: gpflow's optimize() re-runs the Cholesky of the same X, y for
+ * every trial parameter vector).  Synchronous.  After OEI_ERR_NOT_PD the handle stays valid for
+ * another oei_model_refactor, but not for evaluations. */
+int oei_model_refactor(oei_model* m, int kernel_kind, int floor_mode, double variance,
+                       const double* lengthscales, int n_lengthscales, double noise);
 /* fmin, n, d of a model (host outputs). */
 int oei_model_info(const oei_model* m, double* fmin, int* n, int* d);
 /* Copies the n x n lower Cholesky factor L of K + noise*I to a host buffer (diagnostics/tests). */

@@ -29,6 +29,40 @@ def test_nlml_and_gradient_vs_oracle(cuda, n, d, kind, fm, ard):
     assert np.abs(grad - gref).max() <= 1e-7 * (1 + np.abs(gref).max())
 
 
+def test_refactor_in_place_equals_a_new_model(cuda):
+    """New hyper-parameters through oei_model_refactor give the bits a freshly created model gives
+    (factor, fmin, likelihood and its gradient, acquisition value and gradient), also after a trial
+    point whose covariance is not positive definite."""
+    import torch
+    from bayesian_optimization_amd import DeviceGP, _lib
+    rs = np.random.RandomState(8)
+    X = rs.uniform(-.5, .5, (130, 6))
+    y = hart6.normalize(hart6.hart6_scaled(X))[:, 0]
+    Xc = rs.uniform(-.5, .5, (5, 8, 6))
+    gp = DeviceGP(X, y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    gp.nlml()
+    dup = np.vstack([X[:1], X])                                     # duplicate row, zero noise, RBF: singular
+    for var, ls, noise in ((2.3, [0.31], 1e-4), (0.7, [0.9], 1e-2), (1.0, [0.5], 1e-6)):
+        gp.refactor(var, ls, noise)
+        new = DeviceGP(X, y, ogp.KERNEL_MATERN32, var, ls, noise, floor_mode=1)
+        assert gp.fmin == new.fmin and np.array_equal(gp.factor(), new.factor())
+        a, b = gp.nlml(), new.nlml()
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+        for s, t in zip(gp.value_grad(Xc), new.value_grad(Xc)):
+            assert torch.equal(s, t)
+        new.close()
+    sing = DeviceGP(dup, np.concatenate([y[:1], y]), ogp.KERNEL_RBF, 1.0, [0.5], 1e-3, floor_mode=0)
+    with pytest.raises(_lib.OeiError):
+        sing.refactor(1.0, [0.5], 0.0)
+    sing.refactor(1.0, [0.5], 1e-3)                                 # the handle recovers
+    ref = onlml.nlml(dup, np.concatenate([y[:1], y]), ogp.KERNEL_RBF, 1.0, [0.5], 1e-3, floor_mode=0, want_grad=False)[0]
+    assert abs(sing.nlml(want_grad=False)[0] - ref) <= 1e-9 * (1 + abs(ref))
+    with pytest.raises(_lib.OeiError):
+        gp.refactor(-1.0, [0.5], 1e-6)
+    sing.close()
+    gp.close()
+
+
 def test_fit_recovers_better_likelihood(cuda):
     from bayesian_optimization_amd import hyperfit
     rs = np.random.RandomState(4)
