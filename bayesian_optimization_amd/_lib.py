@@ -39,6 +39,13 @@ SIGNATURES = {
     'oei_get_stage_times': (ctypes.c_int, [vp, vp]),
     'oei_argmin': (ctypes.c_int, [ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp]),
     'oei_best_record': (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_longlong, vp, vp]),
+    'oei_lbfgs_layout': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                        ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
+                                        ctypes.POINTER(ctypes.c_size_t)]),
+    'oei_lbfgs_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
+    'oei_lbfgs_advance': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double,
+                                         ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp,
+                                         ctypes.POINTER(ctypes.c_int), vp]),
     'oei_model_nlml': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
 }
 

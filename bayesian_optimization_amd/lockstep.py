@@ -123,6 +123,69 @@ def minimize_lockstep(fun, X0, lower, upper, history=10, max_iter=200, pgtol=1e-
     return LockstepResult(x=x, fun=f, grad=g, nit=nit, nfev=nfev, converged=converged, message=message)
 
 
+LBFGS_D = dict(X=0, F=1, G=2, DIR=3, STEP=4, XT=5, S=6, Y=7, RHO=8, GAMMA=9, XC=10, LO=11, HI=12)
+LBFGS_I = dict(STATUS=0, SLOT=1, NIT=2, NFEV=3, LS=4, FIRST=5, ROWOF=6, MAP=7, COUNT=8, NEED=9)
+LBFGS_STATUS = {0: 'stopped', 1: 'converged', 2: 'converged', 3: 'stopped', 4: 'stopped',
+                5: 'no finite start value', 6: 'stopped'}
+
+
+def minimize_lockstep_device(fun, X0, lower, upper, history=10, max_iter=200, pgtol=1e-5, ftol=2.2e-9,
+                             c1=1e-4, max_ls=25):
+    """minimize_lockstep with the optimiser state and all of its arithmetic in HIP kernels
+    (`oei_lbfgs_*`): per round one call of `fun` on the dense list of trial points and one
+    launch that advances every run -- Armijo test, curvature pair, stopping tests, two-loop
+    direction, next trial point, one wave per run.  Runs do not wait for each other at iteration
+    boundaries, so the number of rounds is the largest number of evaluations any run needs.
+    Same method, constants and result type as minimize_lockstep; X0 must be a GPU tensor."""
+    import ctypes
+    from ._lib import lib, check
+    x0 = torch.as_tensor(X0)
+    if not x0.is_cuda:
+        raise ValueError('minimize_lockstep_device needs GPU tensors (minimize_lockstep is the generic torch version)')
+    x0 = x0.to(torch.float64).contiguous()
+    B, n = x0.shape
+    dev = x0.device
+    lo = torch.as_tensor(lower, dtype=torch.float64, device=dev).expand(n).contiguous()
+    hi = torch.as_tensor(upper, dtype=torch.float64, device=dev).expand(n).contiguous()
+    nd, ni = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    od = (ctypes.c_size_t * len(LBFGS_D))()
+    oi = (ctypes.c_size_t * len(LBFGS_I))()
+    check(lib.oei_lbfgs_layout(B, n, history, ctypes.byref(nd), ctypes.byref(ni), od, oi), 'oei_lbfgs_layout')
+    dws = torch.zeros(nd.value, dtype=torch.float64, device=dev)
+    iws = torch.zeros(ni.value, dtype=torch.int32, device=dev)
+
+    def dview(name, *shape):
+        o = od[LBFGS_D[name]]
+        return dws[o:o + int(torch.Size(shape).numel())].view(*shape)
+
+    def iview(name, count=B):
+        o = oi[LBFGS_I[name]]
+        return iws[o:o + count]
+    indexed = getattr(fun, 'wants_index', False)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.oei_lbfgs_init(B, n, history, p(x0), p(lo), p(hi), p(dws), p(iws), stream), 'oei_lbfgs_init')
+        Xc, rows = dview('XC', B, n), iview('MAP')
+        count = B
+        cnt = ctypes.c_int(0)
+        for _ in range(max(1, max_iter) * max_ls + 2):      # every round ends a trial of every running run
+            ft, gt = fun(Xc[:count], rows[:count].to(torch.int64)) if indexed else fun(Xc[:count])
+            ft = ft.to(torch.float64).contiguous()
+            gt = gt.to(torch.float64).reshape(count, n).contiguous()
+            check(lib.oei_lbfgs_advance(B, n, history, p(ft), p(gt), pgtol, ftol, c1, max_ls, max_iter,
+                                        p(dws), p(iws), ctypes.byref(cnt), stream), 'oei_lbfgs_advance')
+            count = cnt.value
+            if count == 0:
+                break
+    status = iview('STATUS').clone()
+    converged = (status == 1) | (status == 2)
+    message = [LBFGS_STATUS[s] for s in status.tolist()]
+    return LockstepResult(x=dview('X', B, n).clone(), fun=dview('F', B).clone(), grad=dview('G', B, n).clone(),
+                          nit=iview('NIT').to(torch.int64), nfev=iview('NFEV').to(torch.int64),
+                          converged=converged, message=message)
+
+
 def minimize_lockstep_newton(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-5, ftol=2.2e-9,
                              c1=1e-4, max_ls=20):
     """Projected Newton descent of every row of X0 [B, n] in lock-step: the batched consumer of
@@ -289,14 +352,14 @@ def optimize_multistart(gp, X_starts, lower, upper, index_base=0, group=None, pr
                                        **{k: v for k, v in kwargs.items() if k in ('max_iter', 'pgtol', 'ftol')})
         todo = torch.nonzero(~res.converged & torch.isfinite(res.fun)).reshape(-1)
         if todo.numel() > 0:
-            r2 = minimize_lockstep(fun, res.x[todo], lo, hi, **kwargs)
+            r2 = minimize_lockstep_device(fun, res.x[todo], lo, hi, **kwargs)
             res.x[todo], res.fun[todo], res.grad[todo] = r2.x, r2.fun, r2.grad
             res.nit[todo] += r2.nit
             res.nfev[todo] += r2.nfev
             res.converged[todo] = r2.converged
     else:
-        res = minimize_lockstep(acquisition_fun(gp, q, project_fallback, n_runs=B, warm_start=warm_start, stats=stats),
-                                X0, lo, hi, **kwargs)
+        res = minimize_lockstep_device(acquisition_fun(gp, q, project_fallback, n_runs=B, warm_start=warm_start, stats=stats),
+                                       X0, lo, hi, **kwargs)
     fv = torch.where(torch.isfinite(res.fun), res.fun, torch.full_like(res.fun, float('nan')))
     bv, bi = engine.argmin(fv, index_base)
     local = torch.clamp(bi - index_base, min=0)

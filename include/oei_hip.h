@@ -27,6 +27,8 @@
 #ifndef OEI_HIP_H
 #define OEI_HIP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -177,6 +179,73 @@ int oei_argmin(int B, const double* value, long long index_base,
  * X[best] (xlen = q*d doubles) -- the unit of the cross-rank all-gather. */
 int oei_best_record(int B, const double* value, const double* X, int xlen, long long index_base,
                     double* record, void* stream);
+
+/* ---- multistart descent on the device ------------------------------------------------------------
+ * The loop over random starts of bo.py:129-192 (scipy L-BFGS-B per start, solvers.py:10-21) as B
+ * bounded L-BFGS runs that advance together: each round the caller evaluates the objective at a
+ * dense list of trial points and hands value and gradient back; one wave per run then applies the
+ * Armijo test, stores the curvature pair, tests for convergence (projected gradient <= pgtol,
+ * relative decrease <= ftol: the rules of L-BFGS-B), forms the next two-loop direction and the next
+ * trial point.  The objective is whatever the caller evaluates (the acquisition through
+ * oei_value_grad_batched, or the hyper-parameter likelihood): n variables per run, box bounds.
+ *
+ * State lives in two caller-allocated device workspaces (doubles and ints); oei_lbfgs_layout gives
+ * their sizes and the element offsets of the arrays in them:
+ *   doubles  X [B,n] iterate | F [B] value | G [B,n] gradient | DIR [B,n] | STEP [B] | XT [B,n]
+ *            trial point per run | S, Y [B,history,n] pairs | RHO [B,history] | GAMMA [B] |
+ *            XC [B,n] dense list of trial points (rows 0..count) | LO, HI [n]
+ *   ints     STATUS [B] (OEI_LBFGS_*) | SLOT | NIT [B] accepted steps | NFEV [B] evaluations | LS |
+ *            FIRST | ROWOF [B] row of run r in the list or -1 | MAP [B] run of list row c |
+ *            COUNT [1] | NEED [B] */
+#define OEI_LBFGS_D_X 0
+#define OEI_LBFGS_D_F 1
+#define OEI_LBFGS_D_G 2
+#define OEI_LBFGS_D_DIR 3
+#define OEI_LBFGS_D_STEP 4
+#define OEI_LBFGS_D_XT 5
+#define OEI_LBFGS_D_S 6
+#define OEI_LBFGS_D_Y 7
+#define OEI_LBFGS_D_RHO 8
+#define OEI_LBFGS_D_GAMMA 9
+#define OEI_LBFGS_D_XC 10
+#define OEI_LBFGS_D_LO 11
+#define OEI_LBFGS_D_HI 12
+#define OEI_LBFGS_ND 13
+#define OEI_LBFGS_I_STATUS 0
+#define OEI_LBFGS_I_SLOT 1
+#define OEI_LBFGS_I_NIT 2
+#define OEI_LBFGS_I_NFEV 3
+#define OEI_LBFGS_I_LS 4
+#define OEI_LBFGS_I_FIRST 5
+#define OEI_LBFGS_I_ROWOF 6
+#define OEI_LBFGS_I_MAP 7
+#define OEI_LBFGS_I_COUNT 8
+#define OEI_LBFGS_I_NEED 9
+#define OEI_LBFGS_NI 10
+
+#define OEI_LBFGS_RUNNING      0
+#define OEI_LBFGS_CONV_PG      1   /* projected gradient below pgtol */
+#define OEI_LBFGS_CONV_F       2   /* relative decrease below ftol */
+#define OEI_LBFGS_LS_FAILED    3   /* max_ls trial points rejected */
+#define OEI_LBFGS_STALLED      4   /* zero search direction */
+#define OEI_LBFGS_BAD_START    5   /* objective not finite at the start */
+#define OEI_LBFGS_ITER_LIMIT   6
+
+/* Host-only: sizes (elements) of the two workspaces and, optionally, the offsets of the
+ * OEI_LBFGS_ND / OEI_LBFGS_NI arrays inside them. */
+int oei_lbfgs_layout(int B, int n, int history, size_t* n_doubles, size_t* n_ints,
+                     size_t* off_doubles, size_t* off_ints);
+/* x = X0 clipped to the box (X0 [B,n], lower/upper [n], device); every run asks for its start:
+ * XC = x, COUNT = B. */
+int oei_lbfgs_init(int B, int n, int history, const double* X0, const double* lower,
+                   const double* upper, double* dws, int* iws, void* stream);
+/* ft [count], gt [count,n] (device): objective and gradient at the rows of XC written by the
+ * previous call (+inf / NaN values are rejected trial points).  Advances every running run and
+ * writes the next list.  With count_host != NULL the call waits for the stream and returns the
+ * new COUNT there (0: all runs have stopped). */
+int oei_lbfgs_advance(int B, int n, int history, const double* ft, const double* gt,
+                      double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                      double* dws, int* iws, int* count_host, void* stream);
 
 #ifdef __cplusplus
 }
