@@ -39,6 +39,9 @@ SIGNATURES = {
     'oei_get_stage_times': (ctypes.c_int, [vp, vp]),
     'oei_argmin': (ctypes.c_int, [ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp]),
     'oei_best_record': (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_longlong, vp, vp]),
+    'oei_fit_create': (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'oei_fit_destroy': (ctypes.c_int, [vp]),
+    'oei_fit_nlml_batched': (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, vp]),
     'oei_lbfgs_layout': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
                                         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
                                         ctypes.POINTER(ctypes.c_size_t)]),

@@ -66,10 +66,99 @@ def objective(theta, X, y, kind, floor_mode, ard, fixed_noise, priors, device=No
     return float(value), g
 
 
+class BatchedObjective:
+    """R trial parameter vectors on the same data in one device pass (`oei_fit_nlml_batched`):
+    theta [R, nt] GPU tensor of log-parameters -> (value [R], gradient [R, nt]) GPU tensors."""
+
+    def __init__(self, X, y, kind, floor_mode, ard, fixed_noise, priors, max_batch, device=None):
+        import ctypes
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.OeiError('no GPU visible: the hyper-parameter objective has no CPU fallback')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+        self.nls = X.shape[1] if ard else 1
+        self.fixed_noise = -1.0 if fixed_noise is None else float(fixed_noise)
+        self.nt = 1 + self.nls + (1 if fixed_noise is None else 0)
+        self.priors = int(bool(priors))
+        self.cap = int(max_batch)
+        if floor_mode is None:
+            floor_mode = 0 if kind == 0 else 1
+        handle = ctypes.c_void_p(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.oei_fit_create(ctypes.byref(handle), X.shape[0], X.shape[1],
+                                               X.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+                                               int(kind), int(floor_mode), self.cap), 'oei_fit_create')
+        self._h = handle
+
+    def __call__(self, theta):
+        import ctypes
+        import torch
+        theta = torch.as_tensor(theta, dtype=torch.float64, device=self.device).reshape(-1, self.nt).contiguous()
+        R = theta.shape[0]
+        value = torch.empty(R, dtype=torch.float64, device=self.device)
+        grad = torch.empty((R, self.nt), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib.oei_fit_nlml_batched(self._h, R, ctypes.c_void_p(theta.data_ptr()), self.nls,
+                                                     self.fixed_noise, self.priors, ctypes.c_void_p(value.data_ptr()),
+                                                     ctypes.c_void_p(grad.data_ptr()),
+                                                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       'oei_fit_nlml_batched')
+        return value, grad
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h.value:
+            _lib.lib.oei_fit_destroy(self._h)
+            self._h.value = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def fit(X, y, kind, variance, lengthscales, noise, floor_mode=None, ard=False, fixed_noise=True,
         priors=False, restarts=1, rng=np.random, device=None, maxiter=1000):
-    """Best of `restarts` L-BFGS-B runs (plus the current parameters as a candidate, as
-    bo.py:204-219 does).  Returns dict(variance, lengthscales, noise, nlml)."""
+    """Best of `restarts` bounded L-BFGS runs from random starts, plus the current parameters as
+    a candidate (bo.py:204-219).  The restarts advance together: one batched objective evaluation
+    per round (`oei_fit_nlml_batched`) and the device multistart optimiser
+    (`lockstep.minimize_lockstep_device`), so a fit costs the rounds of its slowest restart.
+    Returns dict(variance, lengthscales, noise, nlml)."""
+    import torch
+    from .lockstep import minimize_lockstep_device
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
+    d = X.shape[1]
+    nls = d if ard else 1
+    ls0 = np.broadcast_to(np.asarray(lengthscales, dtype=np.float64).reshape(-1), (nls,)) if ard \
+        else np.asarray(lengthscales, dtype=np.float64).reshape(-1)[:1]
+    fn = float(noise) if fixed_noise else None
+    theta0 = np.log(np.concatenate([[variance], ls0] + ([] if fixed_noise else [[max(noise, 1e-12)]])))
+    restarts = int(restarts)
+    starts = np.array([rng.randn(theta0.size) for _ in range(restarts)]).reshape(restarts, theta0.size)
+    obj = BatchedObjective(X, y, kind, floor_mode, ard, fn, priors, max(restarts, 1), device=device)
+    try:
+        best_theta, best_val = theta0, float(obj(theta0[None])[0][0])
+        if restarts > 0:
+            res = minimize_lockstep_device(obj, torch.as_tensor(starts, device=obj.device), -12.0, 8.0,
+                                           max_iter=maxiter, max_ls=20)
+            vals = torch.where(torch.isfinite(res.fun), res.fun, torch.full_like(res.fun, float('inf')))
+            k = int(torch.argmin(vals))
+            if float(vals[k]) < best_val:
+                best_theta, best_val = res.x[k].cpu().numpy(), float(vals[k])
+    finally:
+        obj.close()
+    out_noise = float(noise) if fixed_noise else float(np.exp(best_theta[1 + nls]))
+    return dict(variance=float(np.exp(best_theta[0])), lengthscales=np.exp(best_theta[1:1 + nls]),
+                noise=out_noise, nlml=float(best_val))
+
+
+def fit_sequential(X, y, kind, variance, lengthscales, noise, floor_mode=None, ard=False, fixed_noise=True,
+                   priors=False, restarts=1, rng=np.random, device=None, maxiter=1000):
+    """The same fit with one scipy L-BFGS-B run per restart, one after the other, on one device
+    model that is re-factorised per trial point (the reference's order of work, bo.py:194-221)."""
     X = np.ascontiguousarray(X, dtype=np.float64)
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).reshape(-1))
     d = X.shape[1]

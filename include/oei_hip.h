@@ -180,6 +180,24 @@ int oei_argmin(int B, const double* value, long long index_base,
 int oei_best_record(int B, const double* value, const double* X, int xlen, long long index_base,
                     double* record, void* stream);
 
+/* ---- batched objective of the hyper-parameter fit ------------------------------------------------
+ * bo.py:194-221 restarts gpflow's optimize() `model_restarts` times on the same data; the restarts
+ * are independent, so R trial parameter vectors are evaluated in one pass (batch item z owns one
+ * set of npad x npad factors; same kernels as oei_model_create).  theta [R, nt] (device) holds
+ * log(variance), log(lengthscale) x n_lengthscales (1 or d) and, when fixed_noise < 0,
+ * log(noise); with fixed_noise >= 0 the noise variance is that constant (run.py:99).  value [R]
+ * and grad [R, nt] (device) receive the negative log marginal likelihood, plus the negative
+ * log-priors of run.py:95-97 when `priors` != 0, and its gradient with respect to theta; +inf and
+ * a zero gradient where K + noise I is not positive definite.  Asynchronous on `stream`.
+ * X_train [n,d], y [n] are host pointers; max_batch bounds R (device memory: 4 max_batch npad^2
+ * doubles). */
+typedef struct oei_fit oei_fit;
+int oei_fit_create(oei_fit** out, int n, int d, const double* X_train, const double* y,
+                   int kernel_kind, int floor_mode, int max_batch);
+int oei_fit_destroy(oei_fit* f);
+int oei_fit_nlml_batched(oei_fit* f, int R, const double* theta, int n_lengthscales,
+                         double fixed_noise, int priors, double* value, double* grad, void* stream);
+
 /* ---- multistart descent on the device ------------------------------------------------------------
  * The loop over random starts of bo.py:129-192 (scipy L-BFGS-B per start, solvers.py:10-21) as B
  * bounded L-BFGS runs that advance together: each round the caller evaluates the objective at a

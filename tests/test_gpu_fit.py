@@ -63,6 +63,73 @@ def test_refactor_in_place_equals_a_new_model(cuda):
     gp.close()
 
 
+@pytest.mark.parametrize('n,d,kind,fm,ard,free_noise,priors', [(40, 6, ogp.KERNEL_MATERN32, 1, False, False, False),
+                                                                (150, 6, ogp.KERNEL_MATERN32, 2, False, True, True),
+                                                                (70, 4, ogp.KERNEL_RBF, 0, True, False, True),
+                                                                (200, 3, ogp.KERNEL_MATERN32, 1, True, True, False)])
+def test_batched_objective_vs_oracle(cuda, n, d, kind, fm, ard, free_noise, priors):
+    """R parameter vectors in one pass: value and gradient with respect to the log-parameters
+    against the CPU restatement, item by item; an item whose covariance is not positive definite
+    gives +inf and does not disturb its neighbours; a sub-batch gives the same bits."""
+    import torch
+    from bayesian_optimization_amd import hyperfit
+    rs = np.random.RandomState(11)
+    X = rs.uniform(-.5, .5, (n, d))
+    if kind == ogp.KERNEL_RBF:
+        X[1] = X[0]                                   # duplicate row: singular without noise
+    y = hart6.normalize(np.sin(3 * X).sum(axis=1, keepdims=True))[:, 0]
+    nls = d if ard else 1
+    fixed = None if free_noise else 1e-4
+    nt = 1 + nls + (1 if free_noise else 0)
+    R = 7
+    theta = rs.uniform(-1.0, 0.7, (R, nt))
+    if free_noise:
+        theta[:, -1] = rs.uniform(-9, -3, R)
+    obj = hyperfit.BatchedObjective(X, y, kind, fm, ard, fixed, priors, max_batch=R)
+    value, grad = [t.cpu().numpy() for t in obj(torch.as_tensor(theta, device=cuda))]
+    for z in range(R):
+        var, ls = np.exp(theta[z, 0]), np.exp(theta[z, 1:1 + nls])
+        noise = np.exp(theta[z, -1]) if free_noise else fixed
+        ref, gref = onlml.nlml(X, y, kind, var, ls, noise, floor_mode=fm)
+        pv, dvar, dls = hyperfit._neg_log_prior(var, ls, priors)
+        gt = np.concatenate([[(gref[0] + dvar) * var], (gref[1:1 + nls] + dls) * ls,
+                             [gref[1 + nls] * noise] if free_noise else []])
+        assert abs(value[z] - (ref + pv)) <= 1e-9 * (1 + abs(ref)), z
+        assert np.abs(grad[z] - gt).max() <= 1e-7 * (1 + np.abs(gt).max()), z
+        single = hyperfit.objective(theta[z], X, y, kind, fm, ard, fixed, priors)
+        assert abs(single[0] - value[z]) <= 1e-10 * (1 + abs(value[z]))
+    v2, g2 = obj(torch.as_tensor(theta[2:5], device=cuda))
+    assert np.array_equal(v2.cpu().numpy(), value[2:5]) and np.array_equal(g2.cpu().numpy(), grad[2:5])
+    if kind == ogp.KERNEL_RBF:
+        obj0 = hyperfit.BatchedObjective(X, y, kind, fm, ard, 0.0, priors, max_batch=R)
+        v0, g0 = obj0(torch.as_tensor(theta, device=cuda))
+        # singular in exact arithmetic; rounding decides per item whether a pivot turns non-positive
+        bad = torch.isinf(v0)
+        assert bool(bad.any()) and float(g0[bad].abs().max()) == 0.0 and bool((v0[bad] > 0).all())
+        assert bool(torch.isfinite(v0[~bad]).all())
+        obj0.close()
+    with pytest.raises(Exception):
+        obj(torch.as_tensor(np.zeros((R + 1, nt)), device=cuda))
+    obj.close()
+
+
+def test_batched_fit_matches_sequential_fit(cuda):
+    """All restarts in lock-step on the device against one scipy L-BFGS-B run per restart from the
+    same random starts: the same best likelihood (the optimisers differ, the optimum does not)."""
+    from bayesian_optimization_amd import hyperfit
+    rs = np.random.RandomState(4)
+    X = rs.uniform(-.5, .5, (110, 6))
+    y = hart6.normalize(hart6.hart6_scaled(X))[:, 0]
+    for kw in (dict(fixed_noise=True, ard=False, priors=False), dict(fixed_noise=False, ard=True, priors=True)):
+        a = hyperfit.fit(X, y, ogp.KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=8,
+                         rng=np.random.RandomState(0), **kw)
+        b = hyperfit.fit_sequential(X, y, ogp.KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=8,
+                                    rng=np.random.RandomState(0), **kw)
+        assert abs(a['nlml'] - b['nlml']) <= 1e-5 * (1 + abs(b['nlml'])), (a, b)
+        assert abs(a['variance'] - b['variance']) <= 2e-2 * b['variance']
+        assert np.abs(a['lengthscales'] - b['lengthscales']).max() <= 2e-2 * b['lengthscales'].max()
+
+
 def test_fit_recovers_better_likelihood(cuda):
     from bayesian_optimization_amd import hyperfit
     rs = np.random.RandomState(4)

@@ -30,14 +30,19 @@ def main():
                 k['gp'] = None
             return orig(*a, **k)
         hyperfit.objective = counted
-        hyperfit.fit(X, y, KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=1, rng=np.random.RandomState(0))
+        hyperfit.fit_sequential(X, y, KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=1, rng=np.random.RandomState(0))
         calls[0] = 0
+        t0 = time.perf_counter()
+        res = hyperfit.fit_sequential(X, y, KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=20, rng=np.random.RandomState(0))
+        dt = time.perf_counter() - t0
+        hyperfit.objective = orig
+        print('n=%d: sequential fit with 20 restarts %.3f s, %d objective evaluations, %.2f ms each, nlml %.6f'
+              % (n, dt, calls[0], 1e3 * dt / calls[0], res['nlml']), flush=True)
+        hyperfit.fit(X, y, KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=2, rng=np.random.RandomState(0))
         t0 = time.perf_counter()
         res = hyperfit.fit(X, y, KERNEL_MATERN32, 1.0, 1.0, 1e-6, floor_mode=1, restarts=20, rng=np.random.RandomState(0))
         dt = time.perf_counter() - t0
-        hyperfit.objective = orig
-        print('n=%d: fit with 20 restarts %.3f s, %d objective evaluations, %.2f ms each, nlml %.6f'
-              % (n, dt, calls[0], 1e3 * dt / calls[0], res['nlml']), flush=True)
+        print('n=%d: batched fit with 20 restarts %.3f s, nlml %.6f' % (n, dt, res['nlml']), flush=True)
 
 
 if __name__ == '__main__':
