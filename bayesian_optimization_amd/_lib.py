@@ -49,6 +49,13 @@ SIGNATURES = {
     'oei_lbfgs_advance': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_double,
                                          ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp,
                                          ctypes.POINTER(ctypes.c_int), vp]),
+    'oei_newton_layout': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                                         ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
+                                         ctypes.POINTER(ctypes.c_size_t)]),
+    'oei_newton_init': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
+    'oei_newton_advance': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double,
+                                          ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp,
+                                          ctypes.POINTER(ctypes.c_int), vp]),
     'oei_model_nlml': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
 }
 

@@ -65,7 +65,8 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+// projection on the box; NaN stays NaN (fmin / fmax alone would turn it into a bound)
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v != v ? v : fmin(fmax(v, lo), hi); }
 
 // Start: x = P(X0), every run asks for the evaluation of its start (list = identity).
 __global__ __launch_bounds__(64) void k_lbfgs_init(LbfgsView V, const double* __restrict__ X0,

@@ -275,6 +275,70 @@ def minimize_lockstep_newton(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-
     return LockstepResult(x=x, fun=f, grad=g, nit=nit, nfev=nfev, converged=converged, message=message)
 
 
+NEWTON_D = dict(X=0, F=1, G=2, DIR=3, STEP=4, XT=5, XC=6, XH=7, LO=8, HI=9)
+NEWTON_I = dict(STATUS=0, NIT=1, NFEV=2, NHEV=3, LS=4, PHASE=5, ROWOF=6, MAP_T=7, MAP_H=8, COUNTS=9, NEED=10)
+NEWTON_MAX_N = 141
+
+
+def minimize_lockstep_newton_device(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-5, ftol=2.2e-9,
+                                    c1=1e-4, max_ls=20):
+    """minimize_lockstep_newton with the state, the Levenberg ladder, the Cholesky factorisation
+    and the line search in HIP kernels (`oei_newton_*`, one workgroup per run).  Per round the
+    host evaluates two dense lists -- `fun` on the trial points, `hess` on the iterates that were
+    just accepted -- and one launch advances every run.  n <= 141 variables per run (the factor
+    lives in LDS); X0 must be a GPU tensor."""
+    import ctypes
+    from ._lib import lib, check
+    x0 = torch.as_tensor(X0)
+    if not x0.is_cuda:
+        raise ValueError('minimize_lockstep_newton_device needs GPU tensors')
+    x0 = x0.to(torch.float64).contiguous()
+    B, n = x0.shape
+    dev = x0.device
+    lo = torch.as_tensor(lower, dtype=torch.float64, device=dev).expand(n).contiguous()
+    hi = torch.as_tensor(upper, dtype=torch.float64, device=dev).expand(n).contiguous()
+    nd, ni = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    od = (ctypes.c_size_t * len(NEWTON_D))()
+    oi = (ctypes.c_size_t * len(NEWTON_I))()
+    check(lib.oei_newton_layout(B, n, ctypes.byref(nd), ctypes.byref(ni), od, oi), 'oei_newton_layout')
+    dws = torch.zeros(nd.value, dtype=torch.float64, device=dev)
+    iws = torch.zeros(ni.value, dtype=torch.int32, device=dev)
+
+    def dview(name, *shape):
+        o = od[NEWTON_D[name]]
+        return dws[o:o + int(torch.Size(shape).numel())].view(*shape)
+
+    def iview(name, count=B):
+        o = oi[NEWTON_I[name]]
+        return iws[o:o + count]
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib.oei_newton_init(B, n, p(x0), p(lo), p(hi), p(dws), p(iws), stream), 'oei_newton_init')
+        Xc, Xh = dview('XC', B, n), dview('XH', B, n)
+        n_trial, n_hess = B, 0
+        cnt = (ctypes.c_int * 2)()
+        for _ in range(2 * (max(1, max_iter) * max_ls + 2)):
+            ft = gt = Ht = None
+            if n_trial > 0:
+                ft, gt = fun(Xc[:n_trial])
+                ft = ft.to(torch.float64).contiguous()
+                gt = gt.to(torch.float64).reshape(n_trial, n).contiguous()
+            if n_hess > 0:
+                Ht = hess(Xh[:n_hess]).to(torch.float64).reshape(n_hess, n, n).contiguous()
+            check(lib.oei_newton_advance(B, n, p(ft), p(gt), p(Ht), pgtol, ftol, c1, max_ls, max_iter,
+                                         p(dws), p(iws), cnt, stream), 'oei_newton_advance')
+            n_trial, n_hess = cnt[0], cnt[1]
+            if n_trial == 0 and n_hess == 0:
+                break
+    status = iview('STATUS').clone()
+    converged = (status == 1) | (status == 2)
+    message = [LBFGS_STATUS[s] for s in status.tolist()]
+    return LockstepResult(x=dview('X', B, n).clone(), fun=dview('F', B).clone(), grad=dview('G', B, n).clone(),
+                          nit=iview('NIT').to(torch.int64), nfev=iview('NFEV').to(torch.int64),
+                          converged=converged, message=message)
+
+
 def acquisition_hess_fun(gp, q):
     """Adapter from a DeviceGP to the `hess` of minimize_lockstep_newton: X [b, q*d] -> H [b, q*d, q*d]
     through the batched acquisition_hessian (oei.py:41-64).  Candidates whose solve failed, and
@@ -348,8 +412,9 @@ def optimize_multistart(gp, X_starts, lower, upper, index_base=0, group=None, pr
         # exact second-order steps on the batched Hessian, then the first-order method polishes
         # the runs the Newton iteration left unconverged (it stops at the first rejected step)
         fun = acquisition_fun(gp, q, project_fallback, stats=stats)
-        res = minimize_lockstep_newton(fun, acquisition_hess_fun(gp, q), X0, lo, hi,
-                                       **{k: v for k, v in kwargs.items() if k in ('max_iter', 'pgtol', 'ftol')})
+        newton = minimize_lockstep_newton_device if q * d <= NEWTON_MAX_N else minimize_lockstep_newton
+        res = newton(fun, acquisition_hess_fun(gp, q), X0, lo, hi,
+                     **{k: v for k, v in kwargs.items() if k in ('max_iter', 'pgtol', 'ftol')})
         todo = torch.nonzero(~res.converged & torch.isfinite(res.fun)).reshape(-1)
         if todo.numel() > 0:
             r2 = minimize_lockstep_device(fun, res.x[todo], lo, hi, **kwargs)

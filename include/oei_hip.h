@@ -265,6 +265,52 @@ int oei_lbfgs_advance(int B, int n, int history, const double* ft, const double*
                       double pgtol, double ftol, double c1, int max_ls, int max_iter,
                       double* dws, int* iws, int* count_host, void* stream);
 
+/* The same for the projected Newton iteration that consumes the exact Hessian (the role of the
+ * reference's SQP solver with `--hessian 1`, solvers.py:56-69, 71-141): a running run waits either
+ * for value and gradient at its trial point (list XC, COUNTS[0] rows) or for the Hessian at its
+ * iterate (list XH, COUNTS[1] rows).  Direction: (H + lam I) d = -g on the variables not blocked at
+ * a bound, lam from the ladder 0, 1e-4 s, 1e-3 s, ... (s = max |H_ij|, 12 steps) until the matrix is
+ * positive definite, else steepest descent; projected backtracking (step / 4), stopping rules as
+ * above.  The factor lives in LDS: n <= OEI_NEWTON_MAX_N variables per run.
+ *   doubles  X | F | G | DIR | STEP | XT | XC [B,n] trial list | XH [B,n] Hessian list | LO | HI
+ *   ints     STATUS (OEI_LBFGS_* codes) | NIT | NFEV | NHEV Hessian evaluations | LS | PHASE |
+ *            ROWOF row of run r in its list | MAP_T, MAP_H run of a list row | COUNTS [2] | NEED */
+#define OEI_NEWTON_MAX_N 141
+#define OEI_NEWTON_D_X 0
+#define OEI_NEWTON_D_F 1
+#define OEI_NEWTON_D_G 2
+#define OEI_NEWTON_D_DIR 3
+#define OEI_NEWTON_D_STEP 4
+#define OEI_NEWTON_D_XT 5
+#define OEI_NEWTON_D_XC 6
+#define OEI_NEWTON_D_XH 7
+#define OEI_NEWTON_D_LO 8
+#define OEI_NEWTON_D_HI 9
+#define OEI_NEWTON_ND 10
+#define OEI_NEWTON_I_STATUS 0
+#define OEI_NEWTON_I_NIT 1
+#define OEI_NEWTON_I_NFEV 2
+#define OEI_NEWTON_I_NHEV 3
+#define OEI_NEWTON_I_LS 4
+#define OEI_NEWTON_I_PHASE 5
+#define OEI_NEWTON_I_ROWOF 6
+#define OEI_NEWTON_I_MAP_T 7
+#define OEI_NEWTON_I_MAP_H 8
+#define OEI_NEWTON_I_COUNTS 9
+#define OEI_NEWTON_I_NEED 10
+#define OEI_NEWTON_NI 11
+int oei_newton_layout(int B, int n, size_t* n_doubles, size_t* n_ints,
+                      size_t* off_doubles, size_t* off_ints);
+int oei_newton_init(int B, int n, const double* X0, const double* lower, const double* upper,
+                    double* dws, int* iws, void* stream);
+/* ft [COUNTS[0]], gt [COUNTS[0], n]: objective and gradient at the rows of XC; Ht [COUNTS[1], n, n]:
+ * Hessians at the rows of XH (non-finite entries count as zero; either list may be empty, its
+ * pointers are then not read).  counts_host (int[2], optional): waits for the stream and returns
+ * the new list lengths; both zero: all runs have stopped. */
+int oei_newton_advance(int B, int n, const double* ft, const double* gt, const double* Ht,
+                       double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                       double* dws, int* iws, int* counts_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,3 +128,58 @@ def test_acquisition_multistart_same_result_as_torch_version(cuda):
     one_d = lockstep.minimize_lockstep_device(fun, starts, -0.5, 0.5, max_iter=1)
     one_r = lockstep.minimize_lockstep(fun, starts, -0.5, 0.5, max_iter=1)
     assert float((one_d.x - one_r.x).abs().max()) <= 1e-12
+
+
+def _rosen_hess(X):
+    """Dense Hessian of the chained Rosenbrock function, [B, n, n]."""
+    B, n = X.shape
+    H = torch.zeros(B, n, n, dtype=X.dtype, device=X.device)
+    a, b = X[:, :-1], X[:, 1:]
+    i = torch.arange(n - 1, device=X.device)
+    H[:, i, i] += 1200.0 * a * a - 400.0 * b + 2.0
+    H[:, i + 1, i + 1] += 200.0
+    H[:, i, i + 1] += -400.0 * a
+    H[:, i + 1, i] += -400.0 * a
+    return H
+
+
+def test_newton_device_matches_torch_version(cuda):
+    """Projected Newton with the state in HIP kernels against the torch statement of the same
+    method: non-convex chained Rosenbrock (the Levenberg ladder is needed away from the valley),
+    an active upper bound, n = 9 and n = 130 (a factor of 130 x 131 doubles in LDS)."""
+    from bayesian_optimization_amd.lockstep import minimize_lockstep_newton, minimize_lockstep_newton_device
+    for n, B in ((9, 21), (130, 5)):
+        X0 = torch.as_tensor(np.random.RandomState(n).uniform(-1.5, 1.5, (B, n)), device=cuda)
+        dev = minimize_lockstep_newton_device(_rosen, _rosen_hess, X0, -2.0, 0.8, max_iter=200)
+        ref = minimize_lockstep_newton(_rosen, _rosen_hess, X0, -2.0, 0.8, max_iter=200)
+        assert int(dev.converged.sum()) >= int(ref.converged.sum()) - 1
+        both = dev.converged & ref.converged
+        assert int(both.sum()) >= B // 2
+        assert float((dev.fun[both] - ref.fun[both]).abs().max()) <= 1e-6 * (1 + float(ref.fun[both].abs().max()))
+        assert bool((dev.x <= 0.8).all()) and bool((dev.x >= -2.0).all())
+        f2, g2 = _rosen(dev.x)
+        assert torch.allclose(f2, dev.fun, rtol=1e-12, atol=0.0)      # torch's sum order depends on the batch shape
+        pg = dev.x - torch.clamp(dev.x - g2, -2.0, 0.8)
+        assert float(pg[dev.converged].abs().max()) <= 1e-3
+        # one iteration from the same start: same ladder, same factor, same accepted point
+        one_d = minimize_lockstep_newton_device(_rosen, _rosen_hess, X0, -2.0, 0.8, max_iter=1)
+        one_r = minimize_lockstep_newton(_rosen, _rosen_hess, X0, -2.0, 0.8, max_iter=1)
+        assert torch.equal(one_d.nfev, one_r.nfev)
+        assert float((one_d.x - one_r.x).abs().max()) <= 1e-9 * (1 + float(one_r.x.abs().max()))
+
+
+def test_newton_device_useless_hessian_and_limits(cuda):
+    from bayesian_optimization_amd import _lib
+    from bayesian_optimization_amd.lockstep import minimize_lockstep_newton_device
+    X0 = torch.as_tensor(np.random.RandomState(3).uniform(-1.5, 1.5, (6, 4)), device=cuda)
+    nan_h = lambda X: torch.full((X.shape[0], 4, 4), float('nan'), dtype=X.dtype, device=X.device)
+    res = minimize_lockstep_newton_device(_rosen, nan_h, X0, -2.0, 0.8, max_iter=5)
+    assert bool((res.fun <= _rosen(X0)[0]).all()) and int(res.nit.max()) <= 5
+    neg_h = lambda X: -_rosen_hess(X).abs() - torch.eye(4, dtype=X.dtype, device=X.device)      # never positive definite at lam = 0
+    res = minimize_lockstep_newton_device(_rosen, neg_h, X0, -2.0, 0.8, max_iter=8)
+    assert bool((res.fun < _rosen(X0)[0]).all())
+    X0[2] = float('nan')
+    res = minimize_lockstep_newton_device(_rosen, _rosen_hess, X0, -2.0, 0.8)
+    assert res.message[2] == 'no finite start value' and bool(res.converged[[0, 1, 3, 4, 5]].all())
+    with pytest.raises(_lib.OeiError):
+        minimize_lockstep_newton_device(_rosen, _rosen_hess, torch.zeros(2, 142, dtype=torch.float64, device=cuda), -2.0, 0.8)

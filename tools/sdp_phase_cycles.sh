@@ -3,7 +3,7 @@
 # the SDP solver spends per phase for one wave.  Run from the repo root on a GPU box.
 set -e
 D=$(mktemp -d)
-for f in oei_model oei_gemm oei_sdp oei_acq oei_hess oei_fit oei_lbfgs; do
+for f in oei_model oei_gemm oei_sdp oei_acq oei_hess oei_fit oei_lbfgs oei_newton; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 --offload-arch=gfx950 -DOEI_SDP_TIMING -c bayesian_optimization_amd/csrc/$f.hip -o $D/$f.o 2>/dev/null &
 done
 wait
