@@ -1290,7 +1290,11 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         // (from a given starting point the first step may already be tiny: no early Jacobi exit)
         const int mode = first ? (warm ? SDP_EVAL_LOOSE : (SDP_EVAL_LOOSE | SDP_EVAL_FIRST))
                                : (SDP_EVAL_WARM | (rel < SDP_STEP_TOL ? 0 : SDP_EVAL_LOOSE));
+        const int sweeps_before = sweeps;
         const double gv = sdp_eval_s<T, Q, EXACT>(w, first ? w.p : w.pn, sweeps, mode);
+        // an eigen-iteration that ran into its sweep limit has not converged: the state is then
+        // reported as "iteration limit", not as solved
+        const bool capped = sweeps - sweeps_before >= SDP_MAX_SWEEPS;
         if (first) {
             first = false;
             g = gv;
@@ -1308,7 +1312,7 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
             __syncthreads();
             g = gv;
             if (!(g > -INFINITY)) { status = 2; break; }
-            if (finish || (full && rel < SDP_STEP_TOL)) { status = 0; break; }
+            if (finish || (full && rel < SDP_STEP_TOL)) { status = capped ? 1 : 0; break; }
         }
         if (++it > SDP_MAX_NEWTON) break;
         SDP_TIC(t_dir);

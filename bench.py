@@ -233,7 +233,7 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         evals_per_s = total * args.steps / dt
-        roofline = hessian = cpu = None
+        roofline = hessian = cpu = callers = None
         if not cpu_only:
             # ---- roofline of the dominant kernel, measured live with HIP events on its stream ----
             gp.set_profiling(True)
@@ -289,6 +289,29 @@ def main():
                                         'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                         'frac': hfl * hb / th / 1e12 / FP64_PEAK_TFLOPS,
                                         'note': 'whole call (8 launches), wall clock over 3 calls'}}
+            if not args.no_hessian:
+                # the callers of the path, outside the timed region: 2048 multistart descents
+                # through the device optimiser, and a hyper-parameter fit with 20 restarts
+                from bayesian_optimization_amd import hyperfit, lockstep
+                nstart = min(B, 2048)
+                Xs = X_local[:nstart]
+                lockstep.optimize_multistart(gp, Xs[:64], [-0.5] * d, [0.5] * d, max_iter=3)
+                torch.cuda.synchronize()
+                tm = time.perf_counter()
+                res, _ = lockstep.optimize_multistart(gp, Xs, [-0.5] * d, [0.5] * d)
+                torch.cuda.synchronize()
+                tm = time.perf_counter() - tm
+                callers = {'multistart': {'starts': nstart, 'seconds': tm, 'evaluations': int(res.nfev.sum().item()),
+                                          'converged': int(res.converged.sum().item()),
+                                          'method': 'bounded L-BFGS, state on the device (oei_lbfgs_advance)'}}
+                hyperfit.fit(gp.X_train, gp.y_train, gp.kernel_kind, 1.0, 1.0, gp.noise, floor_mode=gp.floor_mode,
+                             restarts=2, rng=np.random.RandomState(0))
+                tf = time.perf_counter()
+                fit = hyperfit.fit(gp.X_train, gp.y_train, gp.kernel_kind, 1.0, 1.0, gp.noise, floor_mode=gp.floor_mode,
+                                   restarts=20, rng=np.random.RandomState(0))
+                tf = time.perf_counter() - tf
+                callers['hyperparameter_fit'] = {'restarts': 20, 'seconds': tf, 'nlml': fit['nlml'],
+                                                 'method': 'all restarts batched (oei_fit_nlml_batched)'}
             if not args.no_cpu_baseline and world == 1:
                 # the CPU restatement of the reference path (oracle) timed on this box's host
                 # cores, on a bounded sample of the benchmark's own candidates
@@ -311,7 +334,7 @@ def main():
             'unconverged': n_bad,
             'best': {'value': float(best[0].item()), 'index': int(best[1].item()),
                      'x_sha1': hashlib.sha1(bx.tobytes()).hexdigest()},
-            'hessian': hessian, 'roofline': roofline, 'cpu_baseline': cpu,
+            'hessian': hessian, 'callers': callers, 'roofline': roofline, 'cpu_baseline': cpu,
         }
         if cpu_only:
             result['data'] = 'synthetic; CPU rehearsal of the launcher (stand-in evaluation, rate meaningless)'

@@ -20,9 +20,9 @@
  *   - per-candidate `status`: 0 = converged, 1 = Newton iteration limit reached (the result is the
  *     last iterate), 2 = numerical breakdown (Omega not positive definite, NaN; outputs are NaN).
  *     Like the reference (sdp.py:53-56: warn and continue) a non-zero status never aborts the
- *     batch.  The eigen-iteration (Jacobi) has a cap of 30 sweeps per evaluation that is not a
- *     status of its own: an evaluation that stops there feeds a Newton step that does not
- *     converge, which ends in status 1; the sweep total is in the high half of `iters`.
+ *     batch.  The eigen-iteration (Jacobi) has a cap of 30 sweeps per evaluation: a solve whose
+ *     final evaluation stopped at that cap also reports status 1; the sweep total is in the high
+ *     half of `iters`.
  */
 #ifndef OEI_HIP_H
 #define OEI_HIP_H

@@ -6,10 +6,16 @@ export TMPDIR=/tmp
 O=gpurun_out/r02
 rm -rf $O && mkdir -p $O
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 bench.py --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/statsh -o statsh --output-format csv -- python3 bench.py --no-cpu-baseline > $O/statsh.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --steps 5 --warmup 1 > $O/fetch.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --steps 5 --warmup 1 > $O/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/cfg3 -o cfg3 --output-format csv -- python3 tools/bench_cfg3.py > $O/cfg3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/hess3 -o hess3 --output-format csv -- python3 tools/bench_hessian_cfg3.py > $O/hess3.log 2>&1 || exit 1
 timeout -k 10 200 python3 tools/bench_model.py > $O/model.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/bench_lockstep.py > $O/lockstep.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/bench_fit.py > $O/fit.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/profile_bo_loop.py > $O/bo_loop.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/profile_bo_loop.py --hessian=0 > $O/bo_loop_lbfgs.log 2>&1 || exit 1
+timeout -k 10 400 bash tools/sdp_phase_cycles.sh 20 4096 > $O/phase_cycles.log 2>&1 || exit 1
 echo done > $O/done
