@@ -254,11 +254,14 @@ def main():
             dom = int(np.argmax(stage))
             sdp_ms = stage[2]
             achieved = fl / (sdp_ms * 1e-3) / 1e12
-            traffic = None
+            traffic = step_bytes = None
             prof_json = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
             if os.path.exists(prof_json):
                 try:
-                    traffic = json.load(open(prof_json)).get('moments_sdp_hbm_bytes_per_launch')
+                    pj = json.load(open(prof_json))
+                    traffic = pj.get('moments_sdp_hbm_bytes_per_launch')
+                    if B == BATCH_SINGLE and q == 20:
+                        step_bytes = pj.get('step_hbm_bytes')
                 except Exception:
                     traffic = None
             roofline = {'bound': 'fp64 VALU issue', 'kernel': 'k_stage2 (posterior moments + SDP solve)',
@@ -267,6 +270,9 @@ def main():
                         'peak_note': 'fp64 vector peak = fp64 matrix peak on MI355X; two thirds of the '
                                      "kernel's flops and nearly all of its time are vector arithmetic",
                         'launch_ms': sdp_ms, 'flops_per_launch': fl,
+                        'hbm_step': None if step_bytes is None else {
+                            'bytes': step_bytes, 'GB/s': step_bytes / (ms_per_step * 1e-3) / 1e9, 'peak': 8000.0,
+                            'note': 'PMC bytes of the five kernels of a step (profiles/pmc_traffic.json) over the measured step time; no kernel of the step is HBM-bound'},
                         'stage_ms': dict(zip(names, [float(x) for x in stage])),
                         'dominant_stage': names[dom],
                         'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
@@ -289,7 +295,7 @@ def main():
                                         'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                         'frac': hfl * hb / th / 1e12 / FP64_PEAK_TFLOPS,
                                         'note': 'whole call (8 launches), wall clock over 3 calls'}}
-            if not args.no_hessian:
+            if not args.no_hessian and world == 1:
                 # the callers of the path, outside the timed region: 2048 multistart descents
                 # through the device optimiser, and a hyper-parameter fit with 20 restarts
                 from bayesian_optimization_amd import hyperfit, lockstep
