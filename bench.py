@@ -269,6 +269,8 @@ def main():
                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic,
                         'peak_note': 'fp64 vector peak = fp64 matrix peak on MI355X; two thirds of the '
                                      "kernel's flops and nearly all of its time are vector arithmetic",
+                        'sustained_note': 'a memory-free loop on this chip sustains 56-58 TFLOP/s of v_fma_f64 and 48-49 '
+                                          'TFLOP/s of v_mfma_f64_16x16x4 (tools/micro/mfma_peak.hip); the GEMM stages run at 47',
                         'launch_ms': sdp_ms, 'flops_per_launch': fl,
                         'hbm_step': None if step_bytes is None else {
                             'bytes': step_bytes, 'GB/s': step_bytes / (ms_per_step * 1e-3) / 1e9, 'peak': 8000.0,
