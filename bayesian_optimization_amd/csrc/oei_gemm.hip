@@ -149,7 +149,7 @@ int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int 
 __device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
                                              const double* __restrict__ Bg0,
                                              double* __restrict__ Cg, int ld, int ldc, int kbeg,
-                                             int kend, double* As, double* Bs) {
+                                             int kend, double* As, double* Bs, int tri) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -184,11 +184,15 @@ __device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
             b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
         }
         const int li = lane & 15, lk = lane >> 4;
+        int tlo = 0, thi = 3;                  // see gemm_tile_nt_tall
+        if (tri == 1 && k0 >= kend - GM_BN) tlo = (k0 - (kend - GM_BN)) / GM_BK;
+        if (tri == 2 && k0 < kbeg + GM_BN) thi = (k0 - kbeg) / GM_BK;
 #pragma unroll
         for (int ks = 0; ks < GM_BK / 4; ++ks) {
             const double av = as[(wave * 16 + li) * GM_LDS + ks * 4 + lk];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (t < tlo || t > thi) continue;
                 const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + lk];
                 acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
             }
@@ -213,7 +217,7 @@ __device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
 __device__ __forceinline__ void gemm_tile_nt_tall(const double* __restrict__ Ag0,
                                                   const double* __restrict__ Bg0,
                                                   double* __restrict__ Cg, int ld, int ldc, int kbeg,
-                                                  int kend, double* As, double* Bs) {
+                                                  int kend, double* As, double* Bs, int tri) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -256,12 +260,18 @@ __device__ __forceinline__ void gemm_tile_nt_tall(const double* __restrict__ Ag0
             b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
         }
         const int li = lane & 15, lk = lane >> 4;
+        // inside the 64 x 64 diagonal block of the triangular operand a 16-column group of the
+        // output only meets non-zero entries in the K steps on its side of the diagonal
+        int tlo = 0, thi = 3;
+        if (tri == 1 && k0 >= kend - GM_BN) tlo = (k0 - (kend - GM_BN)) / GM_BK;
+        if (tri == 2 && k0 < kbeg + GM_BN) thi = (k0 - kbeg) / GM_BK;
 #pragma unroll
         for (int ks = 0; ks < GM_BK / 4; ++ks) {
             const double av0 = as[(wave * 32 + li) * GM_LDS + ks * 4 + lk];
             const double av1 = as[(wave * 32 + 16 + li) * GM_LDS + ks * 4 + lk];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if (t < tlo || t > thi) continue;
                 const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + lk];
                 acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv, acc[0][t], 0, 0, 0);
                 acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv, acc[1][t], 0, 0, 0);
@@ -296,7 +306,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_tall(const double* __restrict__
     const size_t r0 = rb * GM_BM2;
     const int kbeg = lower ? 0 : j0;
     const int kend = lower ? (j0 + GM_BN) : npad;
-    gemm_tile_nt_tall(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+    gemm_tile_nt_tall(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs, lower ? 1 : 2);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
     const size_t r0 = rb * GM_BM;
     const int kbeg = lower ? 0 : j0;
     const int kend = lower ? (j0 + GM_BN) : npad;
-    gemm_tile_nt(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+    gemm_tile_nt(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs, lower ? 1 : 2);
 }
 
 int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,
@@ -422,11 +432,15 @@ __global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__
                 b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
                 b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
             }
+            // L^-T is upper triangular: in the diagonal block (the first four K steps) column
+            // group t of the tile only meets non-zero entries from K step t on
+            const int thi = (k0 < j0 + GM_BN) ? (k0 - j0) / GM_BK : 3;
 #pragma unroll
             for (int ks = 0; ks < GM_BK / 4; ++ks) {
                 const double av = as[(wave * 16 + li) * GM_LDS + ks * 4 + kg];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    if (t > thi) continue;
                     const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + kg];
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
                 }
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
     const int J = t - I * (I + 1) / 2;
     const double* Eb = E + b * (size_t)RP * npad;
     gemm_tile_nt(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad,
-                 G + b * (size_t)RP * RP + (size_t)I * 64 * RP + J * 64, npad, RP, 0, npad, As, Bs);
+                 G + b * (size_t)RP * RP + (size_t)I * 64 * RP + J * 64, npad, RP, 0, npad, As, Bs, 0);
 }
 
 int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st) {
