@@ -772,11 +772,16 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d, qd = q * d, npad = m->npad;
     const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
-    const size_t lds = hess_wide_lds_doubles(q, d) * sizeof(double);     // q > 32 only
+    const size_t lds = hess_wide_lds_doubles(q, d) * sizeof(double);     // wide kernel only
+    // q <= 32 runs on the register-path kernels while a candidate's tables fit in LDS beside one
+    // wave's scratch matrices; past that (q near 32 with d >= 9) the wide kernel, which keeps the
+    // tables in global memory, takes over
+    const bool wide = q > 32 ||
+        (hess_dirs_shared_doubles(q, d) + hess_dirs_wave_doubles(q)) * sizeof(double) > (size_t)160 * 1024;
     // candidates per pass: bounded by the per-candidate workspace (E rows and Gram block, about
     // 2 * RP * (npad + RP / 2) doubles), 2048 when that stays below ~4 GB
     int chunk = 2048;
-    const double per_cand = (double)RP * (2.0 * npad + RP) + (q > 32 ? (double)hess_wide_table_doubles(q, d) : 0.0);
+    const double per_cand = (double)RP * (2.0 * npad + RP) + (wide ? (double)hess_wide_table_doubles(q, d) : 0.0);
     while (chunk > 64 && (double)chunk * per_cand * sizeof(double) > 4e9) chunk /= 2;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int Bc = (B - b0 < chunk) ? B - b0 : chunk;
@@ -784,7 +789,7 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         const size_t zrows = round_up_sz((size_t)Bc * q, 64);
         const size_t zbytes = zrows * npad * sizeof(double);
         const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
-        const size_t sbytes = (q <= 32) ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16
+        const size_t sbytes = !wide ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16
                                         : (size_t)Bc * hess_wide_table_doubles(q, d) * sizeof(double) + 16;
         if ((rc = hess_front(m, Bc, q, Xc, RP, 2 * zbytes + Bc * sizeof(double) + ((Bc + 1) & ~1) * sizeof(int) + sbytes, st))) return rc;
         double* Zb = m->hs + gbytes / sizeof(double);
@@ -800,7 +805,7 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         if ((rc = oei_launch_gemm_nt(Zb, m->LinvT, Wb, zrows, npad, 0, st))) return rc;
         double* Hc = H + (size_t)b0 * qd * qd;
         int* sc = status ? status + b0 : nullptr;
-        if (q <= 32) {
+        if (!wide) {
             // state + flags behind the buffers already carved from m->hs
             double* state = reinterpret_cast<double*>(stb + ((Bc + 1) & ~1));
             int* pflag = reinterpret_cast<int*>(state + (size_t)Bc * hess_state_doubles(q));

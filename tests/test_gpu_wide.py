@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import gp as ogp, hart6, oei as ooei, sdp_ref
 
@@ -118,3 +119,29 @@ def test_hessian_cfg3_shape(cuda):
     assert np.abs(H[g['rows']] - g['H_rows']).max() <= 1e-6 * scale                      # task bar: 1e-3
     assert np.abs(np.diag(H) - g['H_diag']).max() <= 1e-6 * scale
     assert np.linalg.norm(H[g['rows']] - g['H_rows']) <= 1e-6 * np.linalg.norm(g['H_rows'])
+
+
+@pytest.mark.parametrize('n,q,d', [(40, 31, 9), (30, 32, 12), (50, 28, 12)])
+def test_hessian_register_sizes_with_tables_beyond_lds(cuda, n, q, d):
+    """q <= 32 whose per-candidate tables (q d q doubles) no longer fit in LDS beside a wave's
+    scratch matrices: the wide kernel with tables in global memory takes over.  Checked against
+    central differences of the device gradient along random directions and for symmetry."""
+    from bayesian_optimization_amd import DeviceGP
+    om = hart6.make_model(n, d=d, lengthscale=0.5 + 0.05 * d)
+    dm = DeviceGP(om.X, om.y, ogp.KERNEL_MATERN32, om.kernel.variance, om.kernel.lengthscales, om.noise,
+                  floor_mode=om.kernel.floor_mode)
+    rs = np.random.RandomState(q + d)
+    Xs = rs.uniform(-.5, .5, (2, q, d))
+    H, st = dm.hessian(Xs)
+    assert int((st != 0).sum()) == 0
+    x0 = torch.as_tensor(Xs, device=cuda).reshape(2, -1)
+    for _ in range(3):
+        v = torch.as_tensor(rs.randn(2, q * d), device=cuda)
+        v = v / v.norm(dim=1, keepdim=True)
+        h = 1e-5
+        gp_ = dm.value_grad((x0 + h * v).reshape(2, q, d))[1]
+        gm_ = dm.value_grad((x0 - h * v).reshape(2, q, d))[1]
+        fd = (gp_ - gm_).reshape(2, -1) / (2 * h)
+        hv = torch.einsum('bij,bj->bi', H, v)
+        assert float(((hv - fd).abs().amax(dim=1) / fd.abs().amax(dim=1)).max()) <= 1e-5
+    assert float((H - H.transpose(1, 2)).abs().max()) <= 1e-9 * float(H.abs().max())
