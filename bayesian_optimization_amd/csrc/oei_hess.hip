@@ -457,7 +457,10 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     const double* Gb = G + b * (size_t)RP * RP;
     const double* M11 = M11_in + b * (size_t)q * q;
     double* Hb = Hout + b * (size_t)qd * qd;
-    double* DS = tabs + b * hess_wide_table_doubles(q, d);
+    // gridDim.y workgroups share a candidate's directions (small batches): slice s takes the
+    // directions s, s + S, ... and works on its own copy of the tables
+    const int slice = blockIdx.y, nslice = gridDim.y;
+    double* DS = tabs + (b * nslice + slice) * hess_wide_table_doubles(q, d);
     double* k1s = DS + (size_t)qd * q;
     double* k2s = k1s + (size_t)q * q;
     double* Dg = k2s + (size_t)q * q;
@@ -492,8 +495,10 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         if (sdp_newton_dir<T, 0>(w)) st = 2;          // reads U from w.X; w.S (Lc) is free afterwards
     }
     if (st) {
-        for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
-        if (tid == 0 && status) status[b] = 2;
+        if (slice == 0) {
+            for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
+            if (tid == 0 && status) status[b] = 2;
+        }
         return;
     }
     __syncthreads();
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     __syncthreads();
 
     // ---- one sensitivity solve per direction, fused with the contraction ------------------------
-    for (int al = 0; al < qd; ++al) {
+    for (int al = slice; al < qd; al += nslice) {
         const int a = al / d, l = al - a * d;
         __syncthreads();
         if (tid < q) {
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         hess_contract(tid, T, kp, q, RP, a, l, w.X, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
                       (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
     }
-    if (tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
+    if (slice == 0 && tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
 }
 
 // ---- register-path sizes (q <= 32): the same work in two kernels ---------------------------------
@@ -630,9 +635,12 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t b = blockIdx.x;
     double* Hb = Hout + b * (size_t)qd * qd;
+    const int slice = blockIdx.y, nslice = gridDim.y;     // workgroups sharing this candidate's directions
     if (stflag[b]) {
-        for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
-        if (tid == 0 && status) status[b] = stflag[b];
+        if (slice == 0) {
+            for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
+            if (tid == 0 && status) status[b] = stflag[b];
+        }
         return;
     }
     lds_f64* base = (lds_f64*)sm;
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     }
     __syncthreads();
 
-    // ---- directions: wave `wave` takes al = wave, wave + NW, ... ---------------------------------
+    // ---- directions: wave `wave` of slice s takes al = wave + NW s, then every NW * nslice-th ----
     SdpWork w;
     w.q = q; w.LD = LD;
     w.S = U; w.R = R; w.H = L; w.rc = rc; w.sq = sq; w.rp = rp;
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     lds_f64* dNmu = wv0 + 7 * VL;
     lds_f64* wvec = wv0 + 8 * VL;
     sv.c = cv; sv.t1 = t1;
-    for (int al = wave; al < qd; al += NW) {
+    for (int al = wave + NW * slice; al < qd; al += NW * nslice) {
         const int a = al / d, l = al - a * d;
         sens_sync<true>();
         // the row's T_al . T_bm entries come from global memory: ask for them before the solve
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
                       (const lds_f64*)k1s, (const lds_f64*)k2s, (const lds_f64*)Dg, Hb, ttpre);
     }
     // a solve that stopped at the Newton iteration limit (status 1) still gets its Hessian
-    if (tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
+    if (slice == 0 && tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -789,8 +797,12 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         const size_t zrows = round_up_sz((size_t)Bc * q, 64);
         const size_t zbytes = zrows * npad * sizeof(double);
         const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
+        // small batches: several workgroups per candidate share its q d directions (the chip has
+        // 256 CUs and these kernels run one workgroup per CU)
+        int nslice = (Bc <= 128) ? 256 / Bc : 1;
+        if (nslice > 8) nslice = 8;
         const size_t sbytes = !wide ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16
-                                        : (size_t)Bc * hess_wide_table_doubles(q, d) * sizeof(double) + 16;
+                                    : (size_t)Bc * nslice * hess_wide_table_doubles(q, d) * sizeof(double) + 16;
         if ((rc = hess_front(m, Bc, q, Xc, RP, 2 * zbytes + Bc * sizeof(double) + ((Bc + 1) & ~1) * sizeof(int) + sbytes, st))) return rc;
         double* Zb = m->hs + gbytes / sizeof(double);
         double* Wb = Zb + zrows * npad;
@@ -821,7 +833,9 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
 #define LAUNCH_DIRS(TT, QE) do { \
                 const size_t lds_d = shared + (size_t)((TT) / 64) * per_wave; \
                 if ((rc = set_lds_attr((k_hess_dirs<TT, QE>), lds_d))) return rc; \
-                hipLaunchKernelGGL((k_hess_dirs<TT, QE>), dim3(Bc), dim3(TT), lds_d, st, m->kp, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, state, pflag, stb, Hc, sc); } while (0)
+                int ns = nslice, rounds = (qd + (TT) / 64 - 1) / ((TT) / 64); \
+                if (ns > rounds) ns = rounds; \
+                hipLaunchKernelGGL((k_hess_dirs<TT, QE>), dim3(Bc, ns), dim3(TT), lds_d, st, m->kp, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, state, pflag, stb, Hc, sc); } while (0)
             // (an instance specialised for q = 20 was measured slower: its straight-line code
             // spills 160 registers per lane, and the spill traffic costs more than the constants save)
             if (nw >= 8) LAUNCH_DIRS(512, 0); else if (nw >= 4) LAUNCH_DIRS(256, 0);
@@ -830,7 +844,7 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         } else {
             double* tabs = reinterpret_cast<double*>(stb + ((Bc + 1) & ~1));
             if ((rc = set_lds_attr((k_hess_wide<256>), lds))) return rc;
-            hipLaunchKernelGGL((k_hess_wide<256>), dim3(Bc), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, stb, tabs, Hc, sc);
+            hipLaunchKernelGGL((k_hess_wide<256>), dim3(Bc, nslice < qd ? nslice : qd), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, stb, tabs, Hc, sc);
         }
         OEI_HIP_CHECK(hipGetLastError());
     }
