@@ -202,3 +202,43 @@ def test_built_library_keeps_scalar_spill_carriers_in_registers():
     bad, total = check_spills.scan(_lib.LIB_PATH)
     assert total > 40
     assert not bad, bad
+
+
+def test_optimiser_workspace_layouts_and_argument_errors():
+    """oei_lbfgs_layout / oei_newton_layout are host-only: sizes, offsets in header order without
+    overlap, and the shape limits (history, the LDS-resident factor of the Newton step)."""
+    import ctypes
+    from bayesian_optimization_amd import _lib
+    from bayesian_optimization_amd.lockstep import LBFGS_D, LBFGS_I, NEWTON_D, NEWTON_I, NEWTON_MAX_N
+    lib = _lib.lib
+    B, n, m = 37, 120, 10
+    nd, ni = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    od = (ctypes.c_size_t * len(LBFGS_D))()
+    oi = (ctypes.c_size_t * len(LBFGS_I))()
+    assert lib.oei_lbfgs_layout(B, n, m, ctypes.byref(nd), ctypes.byref(ni), od, oi) == 0
+    sizes = dict(X=B * n, F=B, G=B * n, DIR=B * n, STEP=B, XT=B * n, S=B * m * n, Y=B * m * n, RHO=B * m,
+                 GAMMA=B, XC=B * n, LO=n, HI=n)
+    order = sorted(LBFGS_D, key=LBFGS_D.get)
+    for a, b in zip(order, order[1:] + [None]):
+        end = od[LBFGS_D[b]] if b else nd.value
+        assert od[LBFGS_D[a]] + sizes[a] <= end and od[LBFGS_D[a]] % 32 == 0
+    assert oi[LBFGS_I['COUNT']] + 1 <= oi[LBFGS_I['NEED']] and oi[LBFGS_I['NEED']] + B <= ni.value
+    assert lib.oei_lbfgs_layout(B, n, 0, ctypes.byref(nd), ctypes.byref(ni), None, None) == -1
+    assert lib.oei_lbfgs_layout(B, n, 65, ctypes.byref(nd), ctypes.byref(ni), None, None) == -1
+    assert lib.oei_lbfgs_layout(0, n, m, ctypes.byref(nd), ctypes.byref(ni), None, None) == -1
+    od = (ctypes.c_size_t * len(NEWTON_D))()
+    oi = (ctypes.c_size_t * len(NEWTON_I))()
+    assert lib.oei_newton_layout(B, NEWTON_MAX_N, ctypes.byref(nd), ctypes.byref(ni), od, oi) == 0
+    assert od[NEWTON_D['XH']] - od[NEWTON_D['XC']] >= B * NEWTON_MAX_N and oi[NEWTON_I['COUNTS']] + 2 <= oi[NEWTON_I['NEED']]
+    assert lib.oei_newton_layout(B, NEWTON_MAX_N + 1, ctypes.byref(nd), ctypes.byref(ni), None, None) == -1
+    assert 'LDS' in lib.oei_last_error().decode()
+
+
+def test_device_optimisers_refuse_cpu_tensors():
+    import torch
+    from bayesian_optimization_amd import lockstep
+    f = lambda X: ((X * X).sum(dim=1), 2 * X)
+    with pytest.raises(ValueError):
+        lockstep.minimize_lockstep_device(f, torch.zeros(2, 3, dtype=torch.float64), -1.0, 1.0)
+    with pytest.raises(ValueError):
+        lockstep.minimize_lockstep_newton_device(f, lambda X: None, torch.zeros(2, 3, dtype=torch.float64), -1.0, 1.0)
