@@ -745,6 +745,291 @@ __device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* p
     return gval;
 }
 
+// ---- q = 20 exactly: pair-per-lane layout, no LDS traffic inside the Jacobi iteration ------------
+// Lane 16 part + k (k < 10) holds rows 5 part .. 5 part + 4 of the columns at positions 2k ("top")
+// and 2k + 1 ("bottom") of a linear array of 20 columns.  Odd-even transposition ordering: even
+// rounds rotate the pairs (2k, 2k + 1), which sit in one lane; odd rounds the pairs (2k + 1, 2k + 2),
+// for which the top of lane k + 1 visits lane k and goes back (two one-lane DPP shifts inside a
+// 16-lane row).  Every rotation also exchanges its two columns, so the columns travel through the
+// array, are reflected at its ends, and all 190 pairs meet once in the 20 rounds of a sweep.  Where
+// a column ends up does not matter: singular values and vectors are used as an unordered set.
+// The sum of a pair's dot product over the four row groups is two v_permlane*_swap exchanges.
+// Vector-unit instructions only -- the split layout above spends 22 ds_bpermute per round in the
+// LDS pipe that all waves of a CU share -- and on average one moved value per round and lane
+// instead of one per row.
+template <int CTRL, bool ZERO>
+__device__ __forceinline__ double sdp_dpp_move(double keep, double v) {    // lanes without a source: `keep`, or zero
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, 0xf, 0xf, ZERO);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), CTRL, 0xf, 0xf, ZERO);
+    return __hiloint2double(hi, lo);
+}
+// sum over the four 16-lane rows; every lane gets the same bits
+__device__ __forceinline__ double sdp_rowsum4(double v) {
+    const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double x = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    const unsigned xl = __double2loint(x), xh = __double2hiint(x);
+    const auto c = __builtin_amdgcn_permlane32_swap(xl, xl, false, false);
+    const auto d = __builtin_amdgcn_permlane32_swap(xh, xh, false, false);
+    return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+
+// Rotation of the pair (left, right) that annihilates their dot product gamma (formulae of
+// sdp_jacobi_split with i = left, j = right): returns c, sn of  l' = c l - sn r,  r' = sn l + c r
+// and updates the squared norms.
+template <int NR>
+__device__ __forceinline__ double sdp_rsq_steps(double a) {     // hardware seed (2^-23) plus NR Newton steps
+    double y = __builtin_amdgcn_rsq(a);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const double e = fma(-(a * y), y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+// NR: Newton steps of the two reciprocal square roots; one step (1e-13) is enough for evaluations
+// that only steer the Newton iteration.
+template <int NR>
+__device__ __forceinline__ bool sdp_pair_rotation(double gamma, double& nl, double& nr, double tol2, double fin2,
+                                                  double& c, double& sn) {
+    c = 1.0; sn = 0.0;
+    const double g2 = gamma * gamma, aa = nl * nr;
+    const bool rot = g2 > tol2 * aa;
+    if (rot) {
+        const double d = nr - nl;
+        const double hinv = sdp_rsq_steps<NR>(fma(d, d, 4.0 * g2));
+        const double v = fma(0.5 * fabs(d), hinv, 0.5);
+        const double rv = sdp_rsq_steps<NR>(v);          // 1 / c
+        c = v * rv;
+        sn = gamma * hinv * rv;
+        if (d < 0.0) sn = -sn;
+        const double tg = sn * rv * gamma;
+        nl -= tg;
+        nr += tg;
+    }
+    return rot && (g2 > fin2 * aa);
+}
+
+template <int NR>
+__device__ int sdp_jacobi_oe20(double (&gt)[5], double (&gb)[5], double tol2, double fin2) {
+    const int lane = threadIdx.x & 63, k = lane & 15;
+    const bool on = k < 10, last = k == 9;
+    int sweep = 0;
+    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
+        bool rotated = false;
+        double a2 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { a2 += gt[i] * gt[i]; b2 += gb[i] * gb[i]; }
+        double nt = sdp_rowsum4(a2), nb = sdp_rowsum4(b2);       // squared norms of top and bottom
+        for (int r = 0; r < 10; ++r) {
+            {   // even round: (top, bottom) of this lane; the rotated columns change places
+                double dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) dot += gt[i] * gb[i];
+                double c, sn;
+                rotated |= sdp_pair_rotation<NR>(sdp_rowsum4(dot), nt, nb, tol2, fin2, c, sn) && on;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const double l = gt[i], rr = gb[i];
+                    gt[i] = sn * l + c * rr;
+                    gb[i] = c * l - sn * rr;
+                }
+                const double t = nt; nt = nb; nb = t;
+            }
+            {   // odd round: (bottom of this lane, top of the next lane); the last position rests
+                double vis[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) vis[i] = sdp_dpp_move<0x101, true>(0.0, gt[i]);     // row_shl:1
+                double nv = sdp_dpp_move<0x101, true>(0.0, nt);
+                double dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) dot += gb[i] * vis[i];
+                double c, sn;
+                rotated |= sdp_pair_rotation<NR>(sdp_rowsum4(dot), nb, nv, tol2, fin2, c, sn) && on && !last;
+                // lane 9 has no visitor (a zero column): a quarter turn plus the exchange leaves
+                // its bottom column where it is and sends the zero column on
+                const double nb_rot = nb, nv_rot = nv;
+                if (last) { c = 0.0; sn = 1.0; }
+                nb = last ? nb_rot : nv_rot;
+                const double nsend = last ? nv_rot : nb_rot;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const double l = gb[i], rr = vis[i];
+                    gb[i] = sn * l + c * rr;
+                    vis[i] = c * l - sn * rr;
+                }
+#pragma unroll
+                for (int i = 0; i < 5; ++i) gt[i] = sdp_dpp_move<0x111, false>(gt[i], vis[i]);  // row_shr:1, lane 0 keeps its top
+                nt = sdp_dpp_move<0x111, false>(nt, nsend);
+            }
+        }
+        if (!__any(rotated)) { ++sweep; break; }
+    }
+    return sweep;
+}
+
+// The evaluation of sdp_eval_reg for q = 20 exactly with the pair-per-lane layout.  With `warm`, the state of the previous
+// evaluation (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in w.sv) seeds this one:
+// G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
+// Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
+__device__ __forceinline__ double sdp_eval_reg20(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+    constexpr int Q = 20;
+    constexpr bool EXACT = true;
+    const int tid = threadIdx.x;
+    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
+    SDP_TIC(t_setup);
+    // lane tid serves column `me` (its piece of it during the Jacobi iteration); the lanes
+    // tid < q ("act") own the column for everything else
+    const bool act = tid < q;
+    const int me = tid % Q;                       // column served outside the Jacobi iteration
+    const int kpos = tid & 15, part = tid >> 4, r0 = 5 * part;
+    const bool on = kpos < 10;
+    const int ct = on ? 2 * kpos : 0, cb = on ? 2 * kpos + 1 : 0;     // the two columns of this lane
+    const double pme = pt[me];
+    double sum, pmin;
+    if constexpr (EXACT) {
+        sum = 0.0; pmin = INFINITY;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) { const double v = pt[k]; sum += v; pmin = fmin(pmin, v); }
+        SDP_READS_FIRST(Q + 1, 4 * Q);
+    } else {
+        sum = wave_sum(act ? pme : 0.0);
+        pmin = wave_min(act ? pme : INFINITY);
+    }
+    const double p0 = 1.0 - sum;
+    if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
+    const double rsp0 = sdp_rsq(p0), sp0 = p0 * rsp0, ip0 = rsp0 * rsp0;
+    const double gam = sdp_rcp(1.0 + sp0), gamp = gam * rsp0;
+    const double rsme = sdp_rsq(pme), sme = pme * rsme, ipme = rsme * rsme;
+    const double rs_t = w.rs[ct], sv_t = w.sv[ct], rs_b = w.rs[cb], sv_b = w.sv[cb];   // read before this call overwrites them
+    const double pt_t = pt[ct], pt_b = pt[cb];
+    __syncthreads();                    // earlier readers of the vectors are done
+    {
+        double acc = 0.0;               // m = Lc^T p (the strict upper part of Lc is zero)
+#pragma unroll
+        for (int i = 0; i < Q; ++i) acc += w.S[i * LD + me] * pt[i];
+        SDP_READS_FIRST(2 * Q, 2 * Q);
+        if (act) w.tv[tid] = acc;
+    }
+    __syncthreads();
+    lds_f64* GT = w.H;                  // q x q exchange buffer (w.H is free during an evaluation)
+    double gt[5], gb[5];
+    {   // rows r0.. of columns ct, cb of G = s_j (Lc^T e_j - gam m); idle lanes: zeros
+        const double st = on ? pt_t * sdp_rsq(pt_t) : 0.0, sb = on ? pt_b * sdp_rsq(pt_b) : 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double m = gam * w.tv[r0 + i];
+            gt[i] = st * (w.S[ct * LD + r0 + i] - m);
+            gb[i] = sb * (w.S[cb * LD + r0 + i] - m);
+        }
+    }
+    if (mode & SDP_EVAL_WARM) {
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { GT[(r0 + i) * LD + ct] = gt[i] * rs_t; GT[(r0 + i) * LD + cb] = gb[i] * rs_b; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { gt[i] = 0.0; gb[i] = 0.0; }
+#pragma unroll 2
+        for (int j = 0; j < Q; ++j) {
+            const double wpj = w.wp[j];
+            const double vt = on ? fma(sv_t, wpj, w.X[j * LD + ct]) : 0.0;     // s_j V_prev[j][ct]
+            const double vb = on ? fma(sv_b, wpj, w.X[j * LD + cb]) : 0.0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const double g = GT[(r0 + i) * LD + j];
+                gt[i] = fma(g, vt, gt[i]);
+                gb[i] = fma(g, vb, gb[i]);
+            }
+            SDP_READS_FIRST(8, 14);
+        }
+        __syncthreads();
+    }
+    SDP_TOC(0, t_setup);
+    SDP_TIC(t_jac);
+    {
+        const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
+        const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
+        const double fin = (mode & SDP_EVAL_FIRST) ? SDP_JACOBI_FINAL_FIRST : loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
+        sweeps += loose ? sdp_jacobi_oe20<1>(gt, gb, tol * tol, fin * fin) : sdp_jacobi_oe20<2>(gt, gb, tol * tol, fin * fin);
+    }
+    SDP_TOC(1, t_jac);
+    SDP_TIC(t_rest);
+    // singular values = column norms; U = Lc^-T (G V) by back substitution, one column per lane
+    int bad = 0;
+    double sqv = 0.0, su = 0.0;
+    {
+        double n2t = 0.0, n2b = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { n2t += gt[i] * gt[i]; n2b += gb[i] * gb[i]; }
+        n2t = sdp_rowsum4(n2t); n2b = sdp_rowsum4(n2b);
+        if (on && (!(n2t > 0.0) || !(n2b > 0.0))) bad = 1;
+        // the columns go to LDS by column index, their singular values with them
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { GT[(r0 + i) * LD + ct] = gt[i]; GT[(r0 + i) * LD + cb] = gb[i]; }
+            if (part == 0) { w.sq[ct] = sqrt(fmax(n2t, 1e-300)); w.sq[cb] = sqrt(fmax(n2b, 1e-300)); }
+        }
+        __syncthreads();
+        sqv = w.sq[me];
+        double g[Q], u[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) {
+            if (EXACT || k < q) g[k] = GT[k * LD + me];
+            else g[k] = 0.0;
+        }
+        if (EXACT) SDP_READS_FIRST(Q, Q);
+#pragma unroll
+        for (int k = Q - 1; k >= 0; --k) {
+            double acc = 0.0;
+            if (EXACT || k < q) {
+                acc = g[k];
+#pragma unroll
+                for (int r = k + 1; r < Q; ++r) if (EXACT || r < q) acc -= w.S[r * LD + k] * u[r];
+                acc *= w.rc[k];
+            }
+            asm volatile("" : "+v"(acc));      // keeps the arithmetic here (not sunk behind the loads)
+            u[k] = acc;
+            su += acc;
+            if (EXACT) SDP_READS_FIRST(Q, 2 * Q);
+        }
+        if (act) {
+            w.sv[tid] = su; w.rp[tid] = su * ip0;
+            w.s[tid] = sme; w.rs[tid] = rsme; w.ip[tid] = ipme; w.wp[tid] = gamp * pme;
+#pragma unroll
+            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
+        }
+    }
+    bad = __syncthreads_or(bad);
+    if (bad) return -INFINITY;
+    {   // grad_i = (sum_a sq_a U_ia^2) / (2 p_i^2) - (sum_a sq_a rp_a^2)/2 - delta_i: lane i walks row i of U
+        double d = 0.0;
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int a = 0; a < Q; ++a) {
+                const double x = w.X[me * LD + a];
+                d += x * x * w.sq[a];
+                if ((a & 3) == 3) SDP_READS_FIRST(8, 16);
+            }
+        } else {
+#pragma unroll 4
+            for (int a = 0; a < q; ++a) {
+                const double x = w.X[me * LD + a];
+                d += x * x * w.sq[a];
+            }
+        }
+        const double rpa = su * ip0;
+        const double t0 = wave_sum(act ? sqv * rpa * rpa : 0.0);
+        if (act) w.grad[tid] = 0.5 * (d * ipme * ipme - t0) - w.dl[tid];
+    }
+    const double gval = wave_sum(act ? sqv - pme * w.dl[me] : 0.0);
+    __syncthreads();
+    SDP_TOC(2, t_rest);
+    return gval;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Newton direction, register path.  With z = U_i o U_j (pair items), U_i o rp, rp o rp and the
 // scaled kernel K'_ab = sq_a sq_b / (sq_a + sq_b) (upper triangle of w.H; K'_aa = sq_a / 2):
@@ -1173,6 +1458,10 @@ __device__ __forceinline__ int sdp_factor_x(const SdpWork w) {
 }
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ double sdp_eval_x(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+#ifndef SDP_NO_TOURNAMENT
+    if constexpr (Q == 20 && EXACT) return sdp_eval_reg20(w, pt, sweeps, mode);
+    else
+#endif
     if constexpr (Q > 0) return sdp_eval_reg<Q, EXACT>(w, pt, sweeps, mode);
     else return sdp_eval_wide<T>(w, pt, sweeps, mode);
 }
