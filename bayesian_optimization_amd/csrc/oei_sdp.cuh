@@ -151,6 +151,16 @@ __device__ __forceinline__ double sdp_rsq(double a) {
     e = fma(-(a * y), y, 1.0);
     return fma(0.5 * y, e, y);
 }
+template <int NR>
+__device__ __forceinline__ double sdp_rsq_steps(double a) {     // hardware seed (2^-23) plus NR Newton steps
+    double y = __builtin_amdgcn_rsq(a);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const double e = fma(-(a * y), y, 1.0);
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
 // value of lane k (k uniform) in every lane, through the scalar unit instead of the LDS crossbar
 __device__ __forceinline__ double sdp_lane_bcast(double v, int k) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
@@ -457,7 +467,7 @@ __device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps,
 // Cholesky A = L L^T inside one wave: lane i keeps row i (a[k], k <= i, zeros behind) in
 // registers, pivots and multipliers travel through the scalar unit.  On return a[] holds row i of
 // L and dinv = 1/L_ii.  Returns 1 if a pivot is not positive (the arithmetic carries on).
-template <int Q, bool EXACT>
+template <int Q, bool EXACT, int NRS = 2>
 __device__ __forceinline__ int sdp_chol_rows(double (&a)[Q], double& dinv, int q, int lane) {
     int fail = 0;
     dinv = 0.0;
@@ -466,7 +476,7 @@ __device__ __forceinline__ int sdp_chol_rows(double (&a)[Q], double& dinv, int q
         if (EXACT || k < q) {
             const double akk = sdp_lane_bcast(a[k], k);
             if (!(akk > 0.0)) fail = 1;              // identical in every lane
-            const double rinv = sdp_rsq(akk);
+            const double rinv = sdp_rsq_steps<NRS>(akk);
             const double lik = (lane >= k) ? a[k] * rinv : 0.0;
             a[k] = lik;
             if (lane == k) dinv = rinv;
@@ -778,16 +788,6 @@ __device__ __forceinline__ double sdp_rowsum4(double v) {
 // Rotation of the pair (left, right) that annihilates their dot product gamma (formulae of
 // sdp_jacobi_split with i = left, j = right): returns c, sn of  l' = c l - sn r,  r' = sn l + c r
 // and updates the squared norms.
-template <int NR>
-__device__ __forceinline__ double sdp_rsq_steps(double a) {     // hardware seed (2^-23) plus NR Newton steps
-    double y = __builtin_amdgcn_rsq(a);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const double e = fma(-(a * y), y, 1.0);
-        y = fma(0.5 * y, e, y);
-    }
-    return y;
-}
 // NR: Newton steps of the two reciprocal square roots; one step (1e-13) is enough for evaluations
 // that only steer the Newton iteration.
 template <int NR>
@@ -1166,7 +1166,9 @@ __device__ __forceinline__ int sdp_chol_solve_reg(const SdpWork w) {
     }
     if (EXACT) SDP_READS_FIRST(Q, 4 * Q);
     double dinv;
-    if (sdp_chol_rows<Q, EXACT>(a, dinv, q, lane)) return 1;
+    // the factor of the Newton matrix gives a search direction: one Newton step (1e-13) in the
+    // reciprocal square roots of its pivots is ample
+    if (sdp_chol_rows<Q, EXACT, 1>(a, dinv, q, lane)) return 1;
     if (act) {
 #pragma unroll
         for (int k = 0; k < Q; ++k) if ((EXACT || k < q) && k <= lane) w.H[row * LD + k] = a[k];
