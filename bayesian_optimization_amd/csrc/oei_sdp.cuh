@@ -25,8 +25,8 @@
 //
 // Two implementations:
 //   * register path (q <= Q <= 32, one 64-lane wave, template parameter Q > 0): one-sided
-//     (Hestenes) Jacobi with the columns of G in registers (column j spread over the 64/Q lanes
-//     j, j+Q, ...); the pairs of a round exchange columns with wave shuffles, no LDS traffic and
+//     (Hestenes) Jacobi with the columns of G in registers (a pair of columns per lane, odd-even
+//     transposition ordering, columns move between lanes with DPP shifts); no LDS traffic and
 //     no eigenvector accumulation (U follows from a triangular solve with Lc).  The previous U
 //     seeds the next evaluation (G <- G V_prev), which saves sweeps as the Newton steps shrink.
 //     Everything the Newton step
@@ -55,9 +55,6 @@
 // evaluations that only steer the Newton iteration (every one but the last) stop earlier
 #define SDP_JACOBI_TOL_LOOSE 1e-11
 #define SDP_JACOBI_FINAL_LOOSE 1e-5
-#ifndef SDP_UNR_WIDE
-#define SDP_UNR_WIDE 1      // unroll factor of the Jacobi round loop in the Q = 32 instance
-#endif
 #define SDP_EVAL_WARM 1
 #define SDP_EVAL_LOOSE 2
 // the very first evaluation feeds a step of several per cent: it may stop a sweep earlier
@@ -521,252 +518,18 @@ __device__ __forceinline__ int sdp_factor_reg(const SdpWork w) {
 // each holding RS = ceil(Q/P) consecutive rows, so that (nearly) all 64 lanes work on the
 // rotations instead of Q of them.  Sums over a column are formed in one fixed order in every lane
 // of the column, which keeps the rotation decisions and parameters bit-identical across its parts.
-template <int Q>
-__device__ __forceinline__ double sdp_col_sum(double v, int col) {
-    constexpr int P = 64 / Q;
-    double s = __shfl(v, col, 64);
-#pragma unroll
-    for (int pt = 1; pt < P; ++pt) s += __shfl(v, col + Q * pt, 64);
-    return s;
-}
-
-template <int Q, int RS>
-__device__ int sdp_jacobi_split(double (&g)[RS], double tol2, double fin2) {
-    constexpr int P = 64 / Q, UNR = Q <= 20 ? 4 : SDP_UNR_WIDE;
-    const int lane = threadIdx.x & 63;
-    const int col = lane % Q, part = lane / Q;
-    const int poff = (part < P) ? part * Q : 0;       // left-over lanes hold zeros and read part 0
-    int sweep = 0;
-    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
-        bool rotated = false;
-        double a2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < RS; ++k) a2 += g[k] * g[k];
-        double alpha = sdp_col_sum<Q>(a2, col);
-        // round-robin pairing of the columns: column c < Q-1 meets (2r - c) mod (Q-1), the fixed
-        // point of that map meets column Q-1; `base` follows (2r - c) mod (Q-1) incrementally
-        int base = (col < Q - 1) ? ((Q - 1 - col) % (Q - 1)) : 0;
-        // unrolled by four in the small instances: the loop-carried column pieces then stay in
-        // place instead of being copied back at the end of every round (a tenth of the
-        // instructions of a round); the Q = 32 instance has no registers to spare for it
-#pragma unroll UNR
-        for (int r = 0; r < Q - 1; ++r) {
-            int pc = r;                                // partner of column Q-1
-            if (col < Q - 1) pc = (base == col) ? Q - 1 : base;
-            base += 2;
-            if (base >= Q - 1) base -= Q - 1;
-            const int plane = pc + poff;
-            double pg[RS];
-#pragma unroll
-            for (int k = 0; k < RS; ++k) pg[k] = __shfl(g[k], plane, 64);
-            const double beta = __shfl(alpha, plane, 64);
-            double dot = 0.0;
-#pragma unroll
-            for (int k = 0; k < RS; ++k) dot += g[k] * pg[k];
-            const double gamma = sdp_col_sum<Q>(dot, col) ;
-            const bool low = col < pc;
-            double c = 1.0, sg = 0.0;
-            const double g2 = gamma * gamma, aa = alpha * beta;
-            const bool rot = g2 > tol2 * aa;
-            if (rot) {
-                // small-angle rotation that annihilates gamma: with d = alpha_j - alpha_i (i < j) and
-                // h = sqrt(d^2 + 4 gamma^2):  c^2 = (h + |d|) / (2 h),  s = sign(d) gamma / (h c),
-                // t = s / c.  Two reciprocal square roots, no division.
-                const double d = low ? beta - alpha : alpha - beta;
-                const double hinv = sdp_rsq(fma(d, d, 4.0 * g2));
-                const double v = fma(0.5 * fabs(d), hinv, 0.5);
-                const double rv = sdp_rsq(v);                    // 1 / c
-                c = v * rv;
-                double sn = gamma * hinv * rv;
-                if (d < 0.0) sn = -sn;
-                sg = low ? -sn : sn;             // g_i' = c g_i - s g_j ; g_j' = s g_i + c g_j
-                alpha = fma(sg * rv, gamma, alpha);
-            }
-            rotated |= rot && (g2 > fin2 * aa);
-#pragma unroll
-            for (int k = 0; k < RS; ++k) g[k] = c * g[k] + sg * pg[k];
-        }
-        if (!__any(rotated)) { ++sweep; break; }
-    }
-    return sweep;
-}
-
-// Needs w.S = Lc, w.rc = 1/diag(Lc) (sdp_factor_reg).  With `warm`, the state of the previous
-// evaluation (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in w.sv) seeds this one:
-// G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
-// Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
-template <int Q, bool EXACT>
-__device__ __forceinline__ double sdp_eval_reg(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
-    const int tid = threadIdx.x;
-    const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
-    SDP_TIC(t_setup);
-    // lane tid serves column `me` (its piece of it during the Jacobi iteration); the lanes
-    // tid < q ("act") own the column for everything else
-    constexpr int P = 64 / Q, RS = (Q + P - 1) / P;
-    const bool act = tid < q;
-    const int part = tid / Q, r0 = part * RS;
-    const bool live = (part < P) && (tid % Q < q);
-    const int me = (tid % Q < q) ? tid % Q : 0;
-    const double pme = pt[me];
-    double sum, pmin;
-    if constexpr (EXACT) {
-        sum = 0.0; pmin = INFINITY;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) { const double v = pt[k]; sum += v; pmin = fmin(pmin, v); }
-        SDP_READS_FIRST(Q + 1, 4 * Q);
-    } else {
-        sum = wave_sum(act ? pme : 0.0);
-        pmin = wave_min(act ? pme : INFINITY);
-    }
-    const double p0 = 1.0 - sum;
-    if (!(p0 > 0.0) || !(pmin > 0.0)) return -INFINITY;
-    const double rsp0 = sdp_rsq(p0), sp0 = p0 * rsp0, ip0 = rsp0 * rsp0;
-    const double gam = sdp_rcp(1.0 + sp0), gamp = gam * rsp0;
-    const double rsme = sdp_rsq(pme), sme = pme * rsme, ipme = rsme * rsme;
-    const double rs_prev = w.rs[me], sv_prev = w.sv[me];    // read before this call overwrites them
-    __syncthreads();                    // earlier readers of the vectors are done
-    {
-        double acc = 0.0;               // m = Lc^T p (the strict upper part of Lc is zero)
-        if constexpr (EXACT) {
-#pragma unroll
-            for (int i = 0; i < Q; ++i) acc += w.S[i * LD + me] * pt[i];
-            SDP_READS_FIRST(2 * Q, 2 * Q);
-        } else {
-#pragma unroll 4
-            for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
-        }
-        if (act) w.tv[tid] = acc;
-    }
-    __syncthreads();
-    lds_f64* GT = w.H;                  // q x q exchange buffer (w.H is free during an evaluation)
-    double gs[RS];
-    {   // rows r0.. of column j of G = s_j (Lc^T e_j - gam m); idle lanes and padding rows: zeros
-        const double sj = live ? sme : 0.0;
-#pragma unroll
-        for (int k = 0; k < RS; ++k) {
-            const int r = r0 + k;
-            const bool in = r < q;
-            const int rr = in ? r : 0;
-            const double v = w.S[me * LD + rr] - gam * w.tv[rr];
-            gs[k] = in ? sj * v : 0.0;
-        }
-    }
-    if (mode & SDP_EVAL_WARM) {
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < RS; ++k) { const int r = r0 + k; if (r < q) GT[r * LD + me] = gs[k] * rs_prev; }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < RS; ++k) gs[k] = 0.0;
-#pragma unroll 2
-        for (int j = 0; j < q; ++j) {
-            const double vl = fma(sv_prev, w.wp[j], w.X[j * LD + me]);     // s_j V_prev[j][a]
-            const double vj = live ? vl : 0.0;
-#pragma unroll
-            for (int k = 0; k < RS; ++k) {
-                const int r = r0 + k;
-                const double gt = GT[(r < q ? r : 0) * LD + j];
-                gs[k] += (r < q ? gt : 0.0) * vj;
-            }
-            if (EXACT) SDP_READS_FIRST(RS + 2, 3 * RS + 4);
-        }
-        __syncthreads();
-    }
-    SDP_TOC(0, t_setup);
-    SDP_TIC(t_jac);
-    {
-        const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
-        const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
-        const double fin = (mode & SDP_EVAL_FIRST) ? SDP_JACOBI_FINAL_FIRST : loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
-        sweeps += sdp_jacobi_split<Q, RS>(gs, tol * tol, fin * fin);
-    }
-    SDP_TOC(1, t_jac);
-    SDP_TIC(t_rest);
-    // singular values = column norms; U = Lc^-T (G V) by back substitution, one column per lane
-    int bad = 0;
-    double sqv = 0.0, su = 0.0;
-    {
-        double n2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < RS; ++k) n2 += gs[k] * gs[k];
-        const double nrm = sdp_col_sum<Q>(n2, tid % Q);
-        if (act && !(nrm > 0.0)) bad = 1;
-        sqv = sqrt(fmax(nrm, 1e-300));
-        // gather the pieces of each column into its owning lane
-        if (live) {
-#pragma unroll
-            for (int k = 0; k < RS; ++k) { const int r = r0 + k; if (r < q) GT[r * LD + me] = gs[k]; }
-        }
-        __syncthreads();
-        double g[Q], u[Q];
-#pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            if (EXACT || k < q) g[k] = GT[k * LD + me];
-            else g[k] = 0.0;
-        }
-        if (EXACT) SDP_READS_FIRST(Q, Q);
-#pragma unroll
-        for (int k = Q - 1; k >= 0; --k) {
-            double acc = 0.0;
-            if (EXACT || k < q) {
-                acc = g[k];
-#pragma unroll
-                for (int r = k + 1; r < Q; ++r) if (EXACT || r < q) acc -= w.S[r * LD + k] * u[r];
-                acc *= w.rc[k];
-            }
-            asm volatile("" : "+v"(acc));      // keeps the arithmetic here (not sunk behind the loads)
-            u[k] = acc;
-            su += acc;
-            if (EXACT) SDP_READS_FIRST(Q, 2 * Q);
-        }
-        if (act) {
-            w.sq[tid] = sqv; w.sv[tid] = su; w.rp[tid] = su * ip0;
-            w.s[tid] = sme; w.rs[tid] = rsme; w.ip[tid] = ipme; w.wp[tid] = gamp * pme;
-#pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
-        }
-    }
-    bad = __syncthreads_or(bad);
-    if (bad) return -INFINITY;
-    {   // grad_i = (sum_a sq_a U_ia^2) / (2 p_i^2) - (sum_a sq_a rp_a^2)/2 - delta_i: lane i walks row i of U
-        double d = 0.0;
-        if constexpr (EXACT) {
-#pragma unroll
-            for (int a = 0; a < Q; ++a) {
-                const double x = w.X[me * LD + a];
-                d += x * x * w.sq[a];
-                if ((a & 3) == 3) SDP_READS_FIRST(8, 16);
-            }
-        } else {
-#pragma unroll 4
-            for (int a = 0; a < q; ++a) {
-                const double x = w.X[me * LD + a];
-                d += x * x * w.sq[a];
-            }
-        }
-        const double rpa = su * ip0;
-        const double t0 = wave_sum(act ? sqv * rpa * rpa : 0.0);
-        if (act) w.grad[tid] = 0.5 * (d * ipme * ipme - t0) - w.dl[tid];
-    }
-    const double gval = wave_sum(act ? sqv - pme * w.dl[me] : 0.0);
-    __syncthreads();
-    SDP_TOC(2, t_rest);
-    return gval;
-}
-
-// ---- q = 20 exactly: pair-per-lane layout, no LDS traffic inside the Jacobi iteration ------------
-// Lane 16 part + k (k < 10) holds rows 5 part .. 5 part + 4 of the columns at positions 2k ("top")
-// and 2k + 1 ("bottom") of a linear array of 20 columns.  Odd-even transposition ordering: even
+// ---- register path (q <= 32): pair-per-lane layout, no LDS traffic inside the Jacobi iteration ----
+// Lane 16 part + k (k < Q / 2) holds rows (Q / 4) part .. of the columns at positions 2k ("top")
+// and 2k + 1 ("bottom") of a linear array of Q columns (Q = 20: k < 10, five rows, four parts).  Odd-even transposition ordering: even
 // rounds rotate the pairs (2k, 2k + 1), which sit in one lane; odd rounds the pairs (2k + 1, 2k + 2),
 // for which the top of lane k + 1 visits lane k and goes back (two one-lane DPP shifts inside a
 // 16-lane row).  Every rotation also exchanges its two columns, so the columns travel through the
-// array, are reflected at its ends, and all 190 pairs meet once in the 20 rounds of a sweep.  Where
+// array, are reflected at its ends, and all Q (Q - 1) / 2 pairs meet once in the Q rounds of a sweep.  Where
 // a column ends up does not matter: singular values and vectors are used as an unordered set.
 // The sum of a pair's dot product over the four row groups is two v_permlane*_swap exchanges.
-// Vector-unit instructions only -- the split layout above spends 22 ds_bpermute per round in the
-// LDS pipe that all waves of a CU share -- and on average one moved value per round and lane
-// instead of one per row.
+// Vector-unit instructions only: a layout with a column spread over 64 / Q lanes and arbitrary
+// partners (ds_bpermute, 22 per round at Q = 20) ran a quarter slower -- the LDS pipe is what the
+// waves of a CU share.
 template <int CTRL, bool ZERO>
 __device__ __forceinline__ double sdp_dpp_move(double keep, double v) {    // lanes without a source: `keep`, or zero
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, 0xf, 0xf, ZERO);
@@ -785,8 +548,9 @@ __device__ __forceinline__ double sdp_rowsum4(double v) {
     return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
 }
 
-// Rotation of the pair (left, right) that annihilates their dot product gamma (formulae of
-// sdp_jacobi_split with i = left, j = right): returns c, sn of  l' = c l - sn r,  r' = sn l + c r
+// Small-angle rotation of the pair (left, right) that annihilates their dot product gamma: with
+// d = |r|^2 - |l|^2 and h = sqrt(d^2 + 4 gamma^2):  c^2 = (h + |d|) / (2 h),  s = sign(d) gamma / (h c).
+// Two reciprocal square roots, no division.  Returns c, sn of  l' = c l - sn r,  r' = sn l + c r
 // and updates the squared norms.
 // NR: Newton steps of the two reciprocal square roots; one step (1e-13) is enough for evaluations
 // that only steer the Newton iteration.
@@ -811,26 +575,30 @@ __device__ __forceinline__ bool sdp_pair_rotation(double gamma, double& nl, doub
     return rot && (g2 > fin2 * aa);
 }
 
-template <int NR>
-__device__ int sdp_jacobi_oe20(double (&gt)[5], double (&gb)[5], double tol2, double fin2) {
+// Q columns (even, Q / 2 <= 16 positions per row), RP = Q / 4 rows per lane.  Columns and rows beyond
+// the problem size are zero: a zero column meets no rotation and just travels.  After an odd
+// number of sweeps the array is in reverse order (position i holds column Q - 1 - i).
+template <int Q, int NR>
+__device__ int sdp_jacobi_oe(double (&gt)[Q / 4], double (&gb)[Q / 4], double tol2, double fin2) {
+    constexpr int RP = Q / 4, K = Q / 2;
     const int lane = threadIdx.x & 63, k = lane & 15;
-    const bool on = k < 10, last = k == 9;
+    const bool on = k < K, last = k == K - 1;
     int sweep = 0;
     for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
         bool rotated = false;
         double a2 = 0.0, b2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { a2 += gt[i] * gt[i]; b2 += gb[i] * gb[i]; }
+        for (int i = 0; i < RP; ++i) { a2 += gt[i] * gt[i]; b2 += gb[i] * gb[i]; }
         double nt = sdp_rowsum4(a2), nb = sdp_rowsum4(b2);       // squared norms of top and bottom
-        for (int r = 0; r < 10; ++r) {
+        for (int r = 0; r < K; ++r) {
             {   // even round: (top, bottom) of this lane; the rotated columns change places
                 double dot = 0.0;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) dot += gt[i] * gb[i];
+                for (int i = 0; i < RP; ++i) dot += gt[i] * gb[i];
                 double c, sn;
                 rotated |= sdp_pair_rotation<NR>(sdp_rowsum4(dot), nt, nb, tol2, fin2, c, sn) && on;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < RP; ++i) {
                     const double l = gt[i], rr = gb[i];
                     gt[i] = sn * l + c * rr;
                     gb[i] = c * l - sn * rr;
@@ -838,29 +606,29 @@ __device__ int sdp_jacobi_oe20(double (&gt)[5], double (&gb)[5], double tol2, do
                 const double t = nt; nt = nb; nb = t;
             }
             {   // odd round: (bottom of this lane, top of the next lane); the last position rests
-                double vis[5];
+                double vis[RP];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) vis[i] = sdp_dpp_move<0x101, true>(0.0, gt[i]);     // row_shl:1
+                for (int i = 0; i < RP; ++i) vis[i] = sdp_dpp_move<0x101, true>(0.0, gt[i]);    // row_shl:1
                 double nv = sdp_dpp_move<0x101, true>(0.0, nt);
                 double dot = 0.0;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) dot += gb[i] * vis[i];
+                for (int i = 0; i < RP; ++i) dot += gb[i] * vis[i];
                 double c, sn;
                 rotated |= sdp_pair_rotation<NR>(sdp_rowsum4(dot), nb, nv, tol2, fin2, c, sn) && on && !last;
-                // lane 9 has no visitor (a zero column): a quarter turn plus the exchange leaves
-                // its bottom column where it is and sends the zero column on
+                // the last lane has no visitor (a zero column): a quarter turn plus the exchange
+                // leaves its bottom column where it is and sends the zero column on
                 const double nb_rot = nb, nv_rot = nv;
                 if (last) { c = 0.0; sn = 1.0; }
                 nb = last ? nb_rot : nv_rot;
                 const double nsend = last ? nv_rot : nb_rot;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) {
+                for (int i = 0; i < RP; ++i) {
                     const double l = gb[i], rr = vis[i];
                     gb[i] = sn * l + c * rr;
                     vis[i] = c * l - sn * rr;
                 }
 #pragma unroll
-                for (int i = 0; i < 5; ++i) gt[i] = sdp_dpp_move<0x111, false>(gt[i], vis[i]);  // row_shr:1, lane 0 keeps its top
+                for (int i = 0; i < RP; ++i) gt[i] = sdp_dpp_move<0x111, false>(gt[i], vis[i]); // row_shr:1, lane 0 keeps its top
                 nt = sdp_dpp_move<0x111, false>(nt, nsend);
             }
         }
@@ -869,23 +637,25 @@ __device__ int sdp_jacobi_oe20(double (&gt)[5], double (&gb)[5], double tol2, do
     return sweep;
 }
 
-// The evaluation of sdp_eval_reg for q = 20 exactly with the pair-per-lane layout.  With `warm`, the state of the previous
+// The evaluation with the pair-per-lane layout (every register-path size).  With `warm`, the state of the previous
 // evaluation (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in w.sv) seeds this one:
 // G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
 // Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
-__device__ __forceinline__ double sdp_eval_reg20(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
-    constexpr int Q = 20;
-    constexpr bool EXACT = true;
+template <int Q, bool EXACT>
+__device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
+    constexpr int RP = Q / 4, K = Q / 2;
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     SDP_TIC(t_setup);
     // lane tid serves column `me` (its piece of it during the Jacobi iteration); the lanes
     // tid < q ("act") own the column for everything else
     const bool act = tid < q;
-    const int me = tid % Q;                       // column served outside the Jacobi iteration
-    const int kpos = tid & 15, part = tid >> 4, r0 = 5 * part;
-    const bool on = kpos < 10;
-    const int ct = on ? 2 * kpos : 0, cb = on ? 2 * kpos + 1 : 0;     // the two columns of this lane
+    const int me = (EXACT || tid % Q < q) ? tid % Q : 0;      // column served outside the Jacobi iteration
+    const int kpos = tid & 15, part = tid >> 4, r0 = RP * part;
+    const bool lane_on = kpos < K;
+    // the two columns of this lane (column indices beyond q: zero columns, reads clamped)
+    const bool ton = lane_on && (EXACT || 2 * kpos < q), bon = lane_on && (EXACT || 2 * kpos + 1 < q);
+    const int ct = ton ? 2 * kpos : 0, cb = bon ? 2 * kpos + 1 : 0;
     const double pme = pt[me];
     double sum, pmin;
     if constexpr (EXACT) {
@@ -907,53 +677,80 @@ __device__ __forceinline__ double sdp_eval_reg20(const SdpWork w, const lds_f64*
     __syncthreads();                    // earlier readers of the vectors are done
     {
         double acc = 0.0;               // m = Lc^T p (the strict upper part of Lc is zero)
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int i = 0; i < Q; ++i) acc += w.S[i * LD + me] * pt[i];
-        SDP_READS_FIRST(2 * Q, 2 * Q);
+            for (int i = 0; i < Q; ++i) acc += w.S[i * LD + me] * pt[i];
+            SDP_READS_FIRST(2 * Q, 2 * Q);
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
+        }
         if (act) w.tv[tid] = acc;
     }
     __syncthreads();
     lds_f64* GT = w.H;                  // q x q exchange buffer (w.H is free during an evaluation)
-    double gt[5], gb[5];
-    {   // rows r0.. of columns ct, cb of G = s_j (Lc^T e_j - gam m); idle lanes: zeros
-        const double st = on ? pt_t * sdp_rsq(pt_t) : 0.0, sb = on ? pt_b * sdp_rsq(pt_b) : 0.0;
+    double gt[RP], gb[RP];
+    int rr[RP];                         // this lane's rows, clamped; rows beyond q hold zeros
+    bool rin[RP];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const double m = gam * w.tv[r0 + i];
-            gt[i] = st * (w.S[ct * LD + r0 + i] - m);
-            gb[i] = sb * (w.S[cb * LD + r0 + i] - m);
+    for (int i = 0; i < RP; ++i) { rin[i] = EXACT || r0 + i < q; rr[i] = rin[i] ? r0 + i : 0; }
+    {   // rows r0.. of columns ct, cb of G = s_j (Lc^T e_j - gam m); idle lanes: zeros
+        const double st = ton ? pt_t * sdp_rsq(pt_t) : 0.0, sb = bon ? pt_b * sdp_rsq(pt_b) : 0.0;
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const double m = gam * w.tv[rr[i]];
+            gt[i] = rin[i] ? st * (w.S[ct * LD + rr[i]] - m) : 0.0;
+            gb[i] = rin[i] ? sb * (w.S[cb * LD + rr[i]] - m) : 0.0;
         }
     }
     if (mode & SDP_EVAL_WARM) {
-        if (on) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { GT[(r0 + i) * LD + ct] = gt[i] * rs_t; GT[(r0 + i) * LD + cb] = gb[i] * rs_b; }
+        for (int i = 0; i < RP; ++i) {
+            if (ton && rin[i]) GT[rr[i] * LD + ct] = gt[i] * rs_t;
+            if (bon && rin[i]) GT[rr[i] * LD + cb] = gb[i] * rs_b;
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { gt[i] = 0.0; gb[i] = 0.0; }
+        for (int i = 0; i < RP; ++i) { gt[i] = 0.0; gb[i] = 0.0; }
+        if constexpr (EXACT) {
 #pragma unroll 2
-        for (int j = 0; j < Q; ++j) {
-            const double wpj = w.wp[j];
-            const double vt = on ? fma(sv_t, wpj, w.X[j * LD + ct]) : 0.0;     // s_j V_prev[j][ct]
-            const double vb = on ? fma(sv_b, wpj, w.X[j * LD + cb]) : 0.0;
+            for (int j = 0; j < Q; ++j) {
+                const double wpj = w.wp[j];
+                const double vt = ton ? fma(sv_t, wpj, w.X[j * LD + ct]) : 0.0;     // s_j V_prev[j][ct]
+                const double vb = bon ? fma(sv_b, wpj, w.X[j * LD + cb]) : 0.0;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const double g = GT[(r0 + i) * LD + j];
-                gt[i] = fma(g, vt, gt[i]);
-                gb[i] = fma(g, vb, gb[i]);
+                for (int i = 0; i < RP; ++i) {
+                    const double g = GT[rr[i] * LD + j];
+                    gt[i] = fma(g, vt, gt[i]);
+                    gb[i] = fma(g, vb, gb[i]);
+                }
+                SDP_READS_FIRST(RP + 3, 2 * RP + 4);
             }
-            SDP_READS_FIRST(8, 14);
+        } else {
+#pragma unroll 2
+            for (int j = 0; j < q; ++j) {
+                const double wpj = w.wp[j];
+                const double vt = ton ? fma(sv_t, wpj, w.X[j * LD + ct]) : 0.0;
+                const double vb = bon ? fma(sv_b, wpj, w.X[j * LD + cb]) : 0.0;
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const double g = rin[i] ? GT[rr[i] * LD + j] : 0.0;
+                    gt[i] = fma(g, vt, gt[i]);
+                    gb[i] = fma(g, vb, gb[i]);
+                }
+            }
         }
         __syncthreads();
     }
     SDP_TOC(0, t_setup);
     SDP_TIC(t_jac);
+    int nsw;
     {
         const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
         const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
         const double fin = (mode & SDP_EVAL_FIRST) ? SDP_JACOBI_FINAL_FIRST : loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
-        sweeps += loose ? sdp_jacobi_oe20<1>(gt, gb, tol * tol, fin * fin) : sdp_jacobi_oe20<2>(gt, gb, tol * tol, fin * fin);
+        nsw = loose ? sdp_jacobi_oe<Q, 1>(gt, gb, tol * tol, fin * fin) : sdp_jacobi_oe<Q, 2>(gt, gb, tol * tol, fin * fin);
+        sweeps += nsw;
     }
     SDP_TOC(1, t_jac);
     SDP_TIC(t_rest);
@@ -963,14 +760,22 @@ __device__ __forceinline__ double sdp_eval_reg20(const SdpWork w, const lds_f64*
     {
         double n2t = 0.0, n2b = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { n2t += gt[i] * gt[i]; n2b += gb[i] * gb[i]; }
+        for (int i = 0; i < RP; ++i) { n2t += gt[i] * gt[i]; n2b += gb[i] * gb[i]; }
         n2t = sdp_rowsum4(n2t); n2b = sdp_rowsum4(n2b);
-        if (on && (!(n2t > 0.0) || !(n2b > 0.0))) bad = 1;
+        // where the columns are now: the array is reversed after an odd number of sweeps
+        const bool rev = (nsw & 1) != 0;
+        const int ot = rev ? Q - 1 - 2 * kpos : 2 * kpos, ob = rev ? Q - 2 - 2 * kpos : 2 * kpos + 1;
+        const bool wt = lane_on && (EXACT || ot < q), wb = lane_on && (EXACT || ob < q);
+        if ((wt && !(n2t > 0.0)) || (wb && !(n2b > 0.0))) bad = 1;
         // the columns go to LDS by column index, their singular values with them
-        if (on) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { GT[(r0 + i) * LD + ct] = gt[i]; GT[(r0 + i) * LD + cb] = gb[i]; }
-            if (part == 0) { w.sq[ct] = sqrt(fmax(n2t, 1e-300)); w.sq[cb] = sqrt(fmax(n2b, 1e-300)); }
+        for (int i = 0; i < RP; ++i) {
+            if (wt && rin[i]) GT[rr[i] * LD + ot] = gt[i];
+            if (wb && rin[i]) GT[rr[i] * LD + ob] = gb[i];
+        }
+        if (part == 0) {
+            if (wt) w.sq[ot] = sqrt(fmax(n2t, 1e-300));
+            if (wb) w.sq[ob] = sqrt(fmax(n2b, 1e-300));
         }
         __syncthreads();
         sqv = w.sq[me];
@@ -1200,7 +1005,7 @@ __device__ __forceinline__ int sdp_chol_solve_reg(const SdpWork w) {
     return 0;
 }
 
-// w.step = (-hess g)^-1 grad g at the state left by sdp_eval_reg (which stays intact: U in w.X).
+// w.step = (-hess g)^-1 grad g at the state left by sdp_eval_oe (which stays intact: U in w.X).
 // Overwrites w.H (K' above, the factor of A in and below the diagonal), w.ci, w.step.
 template <int Q, bool EXACT>
 __device__ __forceinline__ int sdp_newton_dir_reg(const SdpWork w) {
@@ -1460,11 +1265,7 @@ __device__ __forceinline__ int sdp_factor_x(const SdpWork w) {
 }
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ double sdp_eval_x(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
-#ifndef SDP_NO_TOURNAMENT
-    if constexpr (Q == 20 && EXACT) return sdp_eval_reg20(w, pt, sweeps, mode);
-    else
-#endif
-    if constexpr (Q > 0) return sdp_eval_reg<Q, EXACT>(w, pt, sweeps, mode);
+    if constexpr (Q > 0) return sdp_eval_oe<Q, EXACT>(w, pt, sweeps, mode);
     else return sdp_eval_wide<T>(w, pt, sweeps, mode);
 }
 template <int T, int Q, bool EXACT>
