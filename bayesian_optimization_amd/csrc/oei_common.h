@@ -65,6 +65,12 @@ struct oei_model {
     int profile;      // record stage events in value_grad
     hipEvent_t ev[6];
     int ev_valid;
+    // side streams of the pipelined value+gradient call and the events that tie them to the
+    // caller's stream, created on first use
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
+    int pipeline;     // large value+gradient batches run as two halves on the side streams
+    int n_cu;         // compute units of the device
 };
 
 // ---- device helpers ---------------------------------------------------------------------------

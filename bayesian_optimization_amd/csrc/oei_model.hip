@@ -67,6 +67,11 @@ static void model_free(oei_model* m) {
     hipFree(m->ws0); hipFree(m->ws1); hipFree(m->ws2); hipFree(m->aux); hipFree(m->hs);
     hipFree(m->Dinv); hipFree(m->ftmp); hipFree(m->dscal); hipFree(m->dflag); hipFree(m->Kinv); hipFree(m->nlml_part);
     if (m->ev[0]) for (int i = 0; i < 6; ++i) hipEventDestroy(m->ev[i]);
+    for (int i = 0; i < 2; ++i) {
+        if (m->side[i]) hipStreamDestroy(m->side[i]);
+        if (m->ev_join[i]) hipEventDestroy(m->ev_join[i]);
+    }
+    if (m->ev_fork) hipEventDestroy(m->ev_fork);
     delete m;
 }
 
@@ -145,6 +150,8 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
     int rc = set_hyper(m, kernel_kind, floor_mode, variance, lengthscales, n_lengthscales, noise, "model_create");
     if (rc) { delete m; return rc; }
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; oei_set_error("model_create: hipGetDevice failed"); return OEI_ERR_HIP; }
+    m->pipeline = 1;
+    if (hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device) != hipSuccess) m->n_cu = 0;
     if (m->device < 64) {       // set-up of the allocation-free entry point for this device
         const int src = oei_noalloc_setup_device(m->device);
         if (src != OEI_OK) { delete m; return src; }

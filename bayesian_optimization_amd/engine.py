@@ -97,6 +97,10 @@ class DeviceGP:
     def set_profiling(self, on):
         check(lib.oei_set_profiling(self._h, int(bool(on))), 'oei_set_profiling')
 
+    def set_pipelining(self, on):
+        """Large value+gradient batches as two halves on two internal streams (default on)."""
+        check(lib.oei_set_pipelining(self._h, int(bool(on))), 'oei_set_pipelining')
+
     def stage_times_ms(self):
         """Durations (ms) of [gram, GEMM1, moments+SDP, GEMM2, gradient] of the last profiled call."""
         ms = (ctypes.c_float * 5)()

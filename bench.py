@@ -138,6 +138,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=24.0, help='CPU-baseline budget, all legs together')
     ap.add_argument('--no-hessian', action='store_true', help='skip the Hessian throughput leg (profile runs: keeps the kernel statistics to the timed path)')
+    ap.add_argument('--single-stream', action='store_true',
+                    help='keep every launch of a step on one stream (kernel-trace profiles of whole-batch launches); '
+                         'by default batches of two solver rounds and more run as two halves on two internal streams')
     ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' only for rehearsing N > 1 on one GPU or on the CPU")
     ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses GPU 0')
     ap.add_argument('--rehearse-cpu', action='store_true',
@@ -199,6 +202,8 @@ def main():
         model = hart6.make_model(n)                     # CPU copy: data + hyper-parameters only
         gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, model.kernel.variance,
                       model.kernel.lengthscales, model.noise, floor_mode=model.kernel.floor_mode)
+        if args.single_stream:
+            gp.set_pipelining(False)
 
         def step():
             return multistart.evaluate_and_select(gp, X_local, index_base=lo)
@@ -335,6 +340,9 @@ def main():
                                    'per GPU (seed %d), value+gradient + best-start selection'
                                    % ('cfg2' if world == 1 else 'cfg4 recipe', n, q, d, B, seed),
                        'candidates_total': total, 'candidates_per_gpu': B,
+                       'streams': 'one' if (args.single_stream or cpu_only or B < 4096) else
+                                  'two halves of the batch on two internal streams (the per-stage times of '
+                                  '`roofline` are whole-batch launches on one stream)',
                        'parallelism': 'candidates sharded over %d rank(s) (%s), one GPU each, '
                                       'one all-gather of a %d-byte record'
                                       % (world, ('world size seen by ' + args.backend) if world > 1 else 'no process group',

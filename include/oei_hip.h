@@ -158,6 +158,14 @@ int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* dome
  * milliseconds: [0] gram, [1] GEMM Ks L^-T, [2] moments+SDP, [3] GEMM Z L^-1, [4] gradient. */
 int oei_set_profiling(oei_model* m, int on);
 int oei_get_stage_times(oei_model* m, float* ms5);
+/* No counterpart in the reference.  oei_value_grad_batched and oei_value_grad_warm_batched run
+ * batches of at least two full rounds of the solver kernel (B >= 16 x compute units, q <= 32) as two
+ * halves on two internal streams, so that one half's GEMM and kernel-row launches fill the compute
+ * units the other half's solver waves have already left; the caller's stream waits for both, and
+ * the results are bitwise those of the single-stream call.  On by default; off keeps every launch
+ * on the caller's stream (per-kernel profiles of whole-batch launches; calls under stream
+ * capture, since the first pipelined call creates the streams). */
+int oei_set_pipelining(oei_model* m, int on);
 
 /* ---- hyper-parameter objective ------------------------------------------------------------------
  * Negative log marginal likelihood of the GP behind the handle and its gradient, the objective of

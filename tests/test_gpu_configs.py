@@ -91,6 +91,24 @@ def test_cfg2_full_batch_4096(cuda):
     assert torch.equal(again[0], value) and torch.equal(again[1], grad)       # run-to-run identical
 
 
+def test_two_stream_split_is_bitwise_neutral(cuda):
+    """Batches of two solver rounds and more run as two halves on internal streams: same bits as
+    the single-stream call, also for a batch that does not split evenly into 64-row tiles and for
+    the warm-start outputs; later calls on the caller's stream see the finished results."""
+    om, dm = _mk(310)
+    for B in (4096, 4099):
+        Xd = torch.as_tensor(np.random.RandomState(7).uniform(-.5, .5, (B, 20, 6)), device=cuda)
+        dm.set_pipelining(False)
+        ref = dm.value_grad_warm(Xd, want_iters=True)
+        dm.set_pipelining(True)
+        for _ in range(2):
+            out = dm.value_grad_warm(Xd, want_iters=True)
+            small = dm.value_grad(Xd[:3])                      # reuses the same scratch right behind it
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b)
+            assert torch.equal(small[0], ref[0][:3]) and torch.equal(small[1], ref[1][:3])
+
+
 def test_cfg3_batch_256_strided_sample(cuda):
     """n = 1000, q = 50, d = 10 (wide path): 256 candidates, all converged; a strided sample is
     certified and re-evaluated alone with identical bits."""
