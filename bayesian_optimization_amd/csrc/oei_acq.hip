@@ -770,6 +770,7 @@ static int value_grad_pipelined(oei_model* m, int B, int q, const double* X, dou
     for (int i = 0; i < nstreams; ++i) OEI_HIP_CHECK(hipStreamWaitEvent(m->side[i], m->ev_fork, 0));
     const int d = m->d;
     int c = 0;
+    rc = OEI_OK;
     for (int b0 = 0; b0 < B; b0 += per, ++c) {
         const int bc = (B - b0 < per) ? B - b0 : per;
         const size_t row0 = (size_t)b0 * q * m->npad;
@@ -778,13 +779,13 @@ static int value_grad_pipelined(oei_model* m, int B, int q, const double* X, dou
                             aux + value_grad_aux_doubles(m, b0, q),
                             start_in ? start_in + (size_t)b0 * q : nullptr,
                             start_out ? start_out + (size_t)b0 * q : nullptr, iters ? iters + b0 : nullptr);
-        if (rc) return rc;
+        if (rc) break;                                   // the caller's stream still joins what was enqueued
     }
     for (int i = 0; i < nstreams; ++i) {
         OEI_HIP_CHECK(hipEventRecord(m->ev_join[i], m->side[i]));
         OEI_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join[i], 0));
     }
-    return OEI_OK;
+    return rc;
 }
 
 // Batches of at least two full rounds of the solver kernel (eight one-wave candidates per compute

@@ -198,10 +198,11 @@ extern "C" int oei_model_refactor(oei_model* m, int kernel_kind, int floor_mode,
 extern "C" int oei_model_destroy(oei_model* m) {
     if (!m) return OEI_OK;
     int cur = -1;
+    const int dev = m->device;                            // m is gone after model_free
     const bool have = hipGetDevice(&cur) == hipSuccess;
-    if (!have || cur != m->device) hipSetDevice(m->device);
+    if (!have || cur != dev) hipSetDevice(dev);
     model_free(m);
-    if (have && cur != m->device) hipSetDevice(cur);      // the caller's device stays current
+    if (have && cur != dev) hipSetDevice(cur);            // the caller's device stays current
     return OEI_OK;
 }
 

@@ -42,6 +42,9 @@
 #include <climits>
 #include "oei_common.h"
 
+#ifndef SDP_OE_UNROLL
+#define SDP_OE_UNROLL 2
+#endif
 #define SDP_MAX_NEWTON 60
 #define SDP_MAX_SWEEPS 30
 #define SDP_JACOBI_TOL 1e-15
@@ -464,6 +467,10 @@ __device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps,
 // Cholesky A = L L^T inside one wave: lane i keeps row i (a[k], k <= i, zeros behind) in
 // registers, pivots and multipliers travel through the scalar unit.  On return a[] holds row i of
 // L and dinv = 1/L_ii.  Returns 1 if a pivot is not positive (the arithmetic carries on).
+// (Handing the finished column to the other lanes through an LDS vector instead -- one write and
+// ten two-entry reads per step in place of up to 38 v_readlane -- halves the instruction count of
+// the factorisation and was measured slower, 0.66 against 0.61 ms for the whole kernel: every
+// step then waits for an LDS round trip inside the serial chain of pivots.)
 template <int Q, bool EXACT, int NRS = 2>
 __device__ __forceinline__ int sdp_chol_rows(double (&a)[Q], double& dinv, int q, int lane) {
     int fail = 0;
@@ -590,6 +597,7 @@ __device__ int sdp_jacobi_oe(double (&gt)[Q / 4], double (&gb)[Q / 4], double to
 #pragma unroll
         for (int i = 0; i < RP; ++i) { a2 += gt[i] * gt[i]; b2 += gb[i] * gb[i]; }
         double nt = sdp_rowsum4(a2), nb = sdp_rowsum4(b2);       // squared norms of top and bottom
+#pragma unroll SDP_OE_UNROLL
         for (int r = 0; r < K; ++r) {
             {   // even round: (top, bottom) of this lane; the rotated columns change places
                 double dot = 0.0;
