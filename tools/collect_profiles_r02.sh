@@ -6,10 +6,16 @@ export TMPDIR=/tmp
 O=gpurun_out/r02
 rm -rf $O && mkdir -p $O
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian > $O/stats.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/statsh -o statsh --output-format csv -- python3 bench.py --no-cpu-baseline > $O/statsh.log 2>&1 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --steps 5 --warmup 1 > $O/fetch.log 2>&1 || exit 1
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --steps 5 --warmup 1 > $O/write.log 2>&1 || exit 1
+timeout -k 10 300 python3 bench.py --single-stream --no-cpu-baseline --no-hessian > $O/bench_single.json 2> $O/bench_single.err || exit 1
+timeout -k 10 100 python3 tools/bench_pipeline.py 4096 > $O/pipeline.log 2>&1 || exit 1
+timeout -k 10 100 python3 tools/bench_pipeline.py 8192 >> $O/pipeline.log 2>&1 || exit 1
+# kernel statistics and counters of whole-batch launches: --single-stream (by default a step runs as two
+# halves on two streams, whose kernels overlap and are half the size)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream > $O/stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats2 -o stats2 --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian > $O/stats2.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/statsh -o statsh --output-format csv -- python3 bench.py --no-cpu-baseline --single-stream > $O/statsh.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --steps 5 --warmup 1 > $O/fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --steps 5 --warmup 1 > $O/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/cfg3 -o cfg3 --output-format csv -- python3 tools/bench_cfg3.py > $O/cfg3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/hess3 -o hess3 --output-format csv -- python3 tools/bench_hessian_cfg3.py > $O/hess3.log 2>&1 || exit 1
 timeout -k 10 200 python3 tools/bench_model.py > $O/model.log 2>&1 || exit 1

@@ -8,8 +8,11 @@ python tools/kernel_stats_csv.py $O/cfg3/cfg3_kernel_stats.csv profiles/r02_cfg3
 python tools/kernel_stats_csv.py $O/hess3/hess3_kernel_stats.csv profiles/r02_hess_cfg3_kernel_stats.csv
 python tools/pmc_summary_csv.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv profiles/r02_pmc_hbm.json > /dev/null
 cp $O/bench.json profiles/r02_bench.json
+cp $O/bench_single.json profiles/r02_bench_single_stream.json
+python tools/kernel_stats_csv.py $O/stats2/stats2_kernel_stats.csv profiles/r02_kernel_stats_two_streams.csv
 F='amdgpu.ids\|rocprofv3\|output_stream\|tool.cpp'
 grep -v "$F" $O/cfg3.log > profiles/r02_cfg3.log
+grep -v "$F" $O/pipeline.log > profiles/r02_pipeline.log
 grep -v "$F" $O/hess3.log > profiles/r02_hess_cfg3.log
 grep -v "$F" $O/model.log > profiles/r02_model_create.log
 grep -v "$F" $O/lockstep.log > profiles/r02_lockstep.log
