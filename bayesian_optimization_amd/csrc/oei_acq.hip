@@ -796,14 +796,16 @@ static int value_grad_pipelined(oei_model* m, int B, int q, const double* X, dou
 static int value_grad_auto(oei_model* m, int B, int q, const double* X, double* value, double* grad,
                            int* status, int* flags, hipStream_t st, const double* start_in = nullptr,
                            double* start_out = nullptr, int* iters = nullptr) {
-    if (m->pipeline && !m->profile && q <= 32 && m->n_cu > 0 && B >= 2 * 8 * m->n_cu)
-        return value_grad_pipelined(m, B, q, X, value, grad, status, flags, st, m->ws0, m->ws1, m->ws2, m->aux, 2, 2, start_in, start_out, iters);
+    // m->pipeline: 0 off, 1 the rule above, n >= 2 (diagnostic) n pieces whatever the batch size
+    if (m->pipeline && !m->profile && q <= 32 && m->n_cu > 0 && (m->pipeline > 1 || B >= 2 * 8 * m->n_cu))
+        return value_grad_pipelined(m, B, q, X, value, grad, status, flags, st, m->ws0, m->ws1, m->ws2, m->aux,
+                                    m->pipeline > 1 ? m->pipeline : 2, 2, start_in, start_out, iters);
     return value_grad_run(m, B, q, X, value, grad, status, flags, st, m->ws0, m->ws1, m->ws2, m->aux, start_in, start_out, iters);
 }
 
 extern "C" int oei_set_pipelining(oei_model* m, int on) {
     if (!m) { oei_set_error("set_pipelining: null model"); return OEI_ERR_ARG; }
-    m->pipeline = on ? 1 : 0;
+    m->pipeline = on < 0 ? 0 : on;
     return OEI_OK;
 }
 

@@ -98,8 +98,9 @@ class DeviceGP:
         check(lib.oei_set_profiling(self._h, int(bool(on))), 'oei_set_profiling')
 
     def set_pipelining(self, on):
-        """Large value+gradient batches as two halves on two internal streams (default on)."""
-        check(lib.oei_set_pipelining(self._h, int(bool(on))), 'oei_set_pipelining')
+        """Large value+gradient batches as two halves on two internal streams (default on; an
+        integer n >= 2 forces n pieces at any batch size, for measurements)."""
+        check(lib.oei_set_pipelining(self._h, int(on)), 'oei_set_pipelining')
 
     def stage_times_ms(self):
         """Durations (ms) of [gram, GEMM1, moments+SDP, GEMM2, gradient] of the last profiled call."""

@@ -127,8 +127,9 @@ def launch_ranks(n_ranks, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200,
+                    help='timed steps (a step is about 1.1 ms: the first few dozen run while the GPU clocks still ramp up)')
+    ap.add_argument('--warmup', type=int, default=30)
     ap.add_argument('--batch', type=int, default=0,
                     help='candidate batches per GPU (default: %d on one GPU, %d per GPU on several)'
                          % (BATCH_SINGLE, BATCH_MULTI))

@@ -164,7 +164,8 @@ int oei_get_stage_times(oei_model* m, float* ms5);
  * units the other half's solver waves have already left; the caller's stream waits for both, and
  * the results are bitwise those of the single-stream call.  On by default; off keeps every launch
  * on the caller's stream (per-kernel profiles of whole-batch launches; calls under stream
- * capture, since the first pipelined call creates the streams). */
+ * capture, since the first pipelined call creates the streams).  `on` = 1 selects the rule above;
+ * a value n >= 2 is a diagnostic: n pieces, alternating between the two streams, at any batch size. */
 int oei_set_pipelining(oei_model* m, int on);
 
 /* ---- hyper-parameter objective ------------------------------------------------------------------
