@@ -626,7 +626,8 @@ static int set_lds(K kernel, size_t lds) {
 int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
                       size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
                       double* p_buf, double* M11_buf, double* Z, hipStream_t st,
-                      const double* start_in, double* start_out, int* iters) {
+                      const double* start_in, double* start_out, int* iters,
+                      hipEvent_t ev_start, hipEvent_t ev_stop) {
     int rc;
     if (q * (q + 1) / 2 + q > ITEMS_MAX * (q <= 32 ? 64 : 256)) {
         oei_set_error("stage2: q=%d exceeds the per-thread accumulator budget", q);
@@ -635,7 +636,10 @@ int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const d
 #define LAUNCH_STAGE2(T_, Q_) do { \
         const size_t lds2 = acq_lds_doubles(q, m->d, (Q_) == 0) * sizeof(double); \
         if ((rc = set_lds(k_stage2<T_, Q_>, lds2))) return rc; \
-        hipLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z, start_in, start_out, iters); } while (0)
+        if (ev_start) /* the events take the kernel's own start and end from its dispatch */ \
+            hipExtLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), (uint32_t)lds2, st, ev_start, ev_stop, 0, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, (const double*)m->v, value, status, p_buf, M11_buf, Z, start_in, start_out, iters); \
+        else \
+            hipLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), lds2, st, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, m->v, value, status, p_buf, M11_buf, Z, start_in, start_out, iters); } while (0)
     SDP_DISPATCH_Q(q, LAUNCH_STAGE2);
 #undef LAUNCH_STAGE2
     OEI_HIP_CHECK(hipGetLastError());
@@ -708,7 +712,8 @@ static int value_grad_run(oei_model* m, int B, int q, const double* X, double* v
         oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
         return OEI_ERR_ARG;
     }
-    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, ws0, st, start_in, start_out, iters);
+    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, ws0, st, start_in, start_out, iters,
+                           prof ? m->kev[0] : nullptr, prof ? m->kev[1] : nullptr);
     if (rc) return rc;
     if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
         OEI_HIP_CHECK(hipMemsetAsync(ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
@@ -881,16 +886,17 @@ extern "C" int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const 
 extern "C" int oei_set_profiling(oei_model* m, int on) {
     if (!m) { oei_set_error("set_profiling: null model"); return OEI_ERR_ARG; }
     if (on && !m->ev[0]) {
-        hipEvent_t tmp[6] = {};
-        for (int i = 0; i < 6; ++i) {
+        hipEvent_t tmp[8] = {};
+        for (int i = 0; i < 8; ++i) {
             const hipError_t e = hipEventCreate(&tmp[i]);
-            if (e != hipSuccess) {           // all six or none
+            if (e != hipSuccess) {           // all eight or none
                 for (int j = 0; j < i; ++j) hipEventDestroy(tmp[j]);
                 oei_set_error("set_profiling: hipEventCreate failed: %s", hipGetErrorString(e));
                 return OEI_ERR_HIP;
             }
         }
         for (int i = 0; i < 6; ++i) m->ev[i] = tmp[i];
+        m->kev[0] = tmp[6]; m->kev[1] = tmp[7];
     }
     m->profile = on;
     m->ev_valid = 0;
@@ -902,6 +908,14 @@ extern "C" int oei_get_stage_times(oei_model* m, float* ms5) {
     if (!m->ev_valid) { oei_set_error("get_stage_times: no profiled call recorded"); return OEI_ERR_ARG; }
     OEI_HIP_CHECK(hipEventSynchronize(m->ev[5]));
     for (int i = 0; i < 5; ++i) OEI_HIP_CHECK(hipEventElapsedTime(&ms5[i], m->ev[i], m->ev[i + 1]));
+    return OEI_OK;
+}
+
+extern "C" int oei_get_solver_kernel_time(oei_model* m, float* ms) {
+    if (!m || !ms) { oei_set_error("get_solver_kernel_time: null pointer"); return OEI_ERR_ARG; }
+    if (!m->ev_valid) { oei_set_error("get_solver_kernel_time: no profiled call recorded"); return OEI_ERR_ARG; }
+    OEI_HIP_CHECK(hipEventSynchronize(m->kev[1]));
+    OEI_HIP_CHECK(hipEventElapsedTime(ms, m->kev[0], m->kev[1]));
     return OEI_OK;
 }
 

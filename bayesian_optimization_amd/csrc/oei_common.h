@@ -2,6 +2,7 @@
 // parameter block and small device helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdint>
 #include "../../include/oei_hip.h"
@@ -64,6 +65,7 @@ struct oei_model {
     double* nlml_part;   // [n, 2 + d] per-row gradient terms, allocated on first use
     int profile;      // record stage events in value_grad
     hipEvent_t ev[6];
+    hipEvent_t kev[2];   // start / stop of the solver kernel itself (taken from its dispatch, no launch gaps)
     int ev_valid;
     // side streams of the pipelined value+gradient call and the events that tie them to the
     // caller's stream, created on first use
@@ -129,7 +131,8 @@ int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int 
 int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const double* A,
                       size_t a_cand_stride, size_t a_row_stride, double* value, int* status,
                       double* p_buf, double* M11_buf, double* Z, hipStream_t st,
-                      const double* start_in = nullptr, double* start_out = nullptr, int* iters = nullptr);
+                      const double* start_in = nullptr, double* start_out = nullptr, int* iters = nullptr,
+                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // G_b = E_b E_b^T (lower block-triangle of 64x64 tiles), E [B*RP, npad], G [B, RP, RP].
 int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st);
 // C[r, j] = sum_k A[r, k] * Bm[j, k], all [*, npad] row-major; `lower` != 0 means Bm is lower

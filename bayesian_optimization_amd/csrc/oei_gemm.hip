@@ -110,23 +110,31 @@ __global__ __launch_bounds__(256) void k_gram_ext(KernParams kp, const double* _
     __syncthreads();
     const int kk = tid & 63;
     const int k = k0 + kk;
-    for (int rr = tid >> 6; rr < GR_ROWS; rr += 4) {
-        const int rl = rl0 + rr, a = rl / dp, lp = rl - a * dp;
-        double val = 0.0;
+    // One kernel evaluation per (point, training point) serves the point's value row and its d
+    // derivative rows (they share t and the exponential); a point whose rows straddle two row
+    // groups is evaluated by both.  Wave w takes every fourth point of the group.
+    const int a_lo = rl0 / dp, a_hi = (rl0 + GR_ROWS - 1) / dp;
+    for (int a = a_lo + (tid >> 6); a <= a_hi; a += 4) {
+        const int rbeg = max(a * dp, rl0), rend = min(a * dp + dp, rl0 + GR_ROWS);     // rows [rbeg, rend)
         if (a < q && k < n) {
+            const double* xa = Qs + (rbeg - rl0) * d;    // every row of the group carries its point
             double t = 0.0;
             for (int l = 0; l < d; ++l) {
-                double df = Qs[rr * d + l] - Xs[kk * d + l];
+                const double df = xa[l] - Xs[kk * d + l];
                 t += df * df * kp.inv_ls2[l];
             }
             double k0v, k1v, k2v;
             kappa_eval<1>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
-            if (lp == 0) val = kp.variance * k0v;
-            else val = 2.0 * kp.variance * k1v * (Qs[rr * d + lp - 1] - Xs[kk * d + lp - 1]) * kp.inv_ls2[lp - 1];
-        } else if (rl == q * dp && k < n) {
-            val = y[k];
+            for (int rl = rbeg; rl < rend; ++rl) {
+                const int lp = rl - a * dp;
+                const double val = (lp == 0) ? kp.variance * k0v
+                    : 2.0 * kp.variance * k1v * (xa[lp - 1] - Xs[kk * d + lp - 1]) * kp.inv_ls2[lp - 1];
+                out[(b * RP + rl) * npad + k] = val;
+            }
+        } else {
+            for (int rl = rbeg; rl < rend; ++rl)
+                out[(b * RP + rl) * npad + k] = (rl == q * dp && k < n) ? y[k] : 0.0;
         }
-        out[(r0 + rr) * npad + k] = val;
     }
 }
 

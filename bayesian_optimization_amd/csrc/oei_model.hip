@@ -67,6 +67,7 @@ static void model_free(oei_model* m) {
     hipFree(m->ws0); hipFree(m->ws1); hipFree(m->ws2); hipFree(m->aux); hipFree(m->hs);
     hipFree(m->Dinv); hipFree(m->ftmp); hipFree(m->dscal); hipFree(m->dflag); hipFree(m->Kinv); hipFree(m->nlml_part);
     if (m->ev[0]) for (int i = 0; i < 6; ++i) hipEventDestroy(m->ev[i]);
+    for (int i = 0; i < 2; ++i) if (m->kev[i]) hipEventDestroy(m->kev[i]);
     for (int i = 0; i < 2; ++i) {
         if (m->side[i]) hipStreamDestroy(m->side[i]);
         if (m->ev_join[i]) hipEventDestroy(m->ev_join[i]);

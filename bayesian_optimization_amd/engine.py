@@ -108,6 +108,14 @@ class DeviceGP:
         check(lib.oei_get_stage_times(self._h, ctypes.cast(ms, ctypes.c_void_p)), 'oei_get_stage_times')
         return [float(x) for x in ms]
 
+    def solver_kernel_ms(self):
+        """Duration (ms) of the moments+SDP kernel of the last profiled call, from events attached
+        to its own dispatch (no launch gaps)."""
+        ms = ctypes.c_float()
+        check(lib.oei_get_solver_kernel_time(self._h, ctypes.cast(ctypes.byref(ms), ctypes.c_void_p)),
+              'oei_get_solver_kernel_time')
+        return float(ms.value)
+
     # ---- batched device API -----------------------------------------------------------------
     def nlml(self, want_grad=True, ard=False):
         """Negative log marginal likelihood of the model and its gradient with respect to

@@ -158,6 +158,10 @@ int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* dome
  * milliseconds: [0] gram, [1] GEMM Ks L^-T, [2] moments+SDP, [3] GEMM Z L^-1, [4] gradient. */
 int oei_set_profiling(oei_model* m, int on);
 int oei_get_stage_times(oei_model* m, float* ms5);
+/* Duration (ms) of the moments+SDP kernel of the last profiled call, from start and stop events
+ * attached to its dispatch (hipExtLaunchKernel): the kernel alone, as a kernel trace reports it,
+ * where interval [2] above also holds the launch gap that an event between two kernels opens. */
+int oei_get_solver_kernel_time(oei_model* m, float* ms);
 /* No counterpart in the reference.  oei_value_grad_batched and oei_value_grad_warm_batched run
  * batches of at least two full rounds of the solver kernel (B >= 16 x compute units, q <= 32) as two
  * halves on two internal streams, so that one half's GEMM and kernel-row launches fill the compute
