@@ -838,7 +838,8 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
                 hipLaunchKernelGGL((k_hess_dirs<TT, QE>), dim3(Bc, ns), dim3(TT), lds_d, st, m->kp, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, state, pflag, stb, Hc, sc); } while (0)
             // (an instance specialised for q = 20 was measured slower: its straight-line code
             // spills 160 registers per lane, and the spill traffic costs more than the constants save)
-            if (nw >= 8) LAUNCH_DIRS(512, 0); else if (nw >= 4) LAUNCH_DIRS(256, 0);
+            if (nw >= 12 && qd >= 96) LAUNCH_DIRS(768, 0);
+            else if (nw >= 8) LAUNCH_DIRS(512, 0); else if (nw >= 4) LAUNCH_DIRS(256, 0);
             else if (nw >= 2) LAUNCH_DIRS(128, 0); else LAUNCH_DIRS(64, 0);
 #undef LAUNCH_DIRS
         } else {
