@@ -41,6 +41,7 @@ SIGNATURES = {
     'oei_set_pipelining': (ctypes.c_int, [vp, ctypes.c_int]),
     'oei_argmin': (ctypes.c_int, [ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp]),
     'oei_best_record': (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_longlong, vp, vp]),
+    'oei_select_record': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     'oei_fit_create': (ctypes.c_int, [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'oei_fit_destroy': (ctypes.c_int, [vp]),
     'oei_fit_nlml_batched': (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_double, ctypes.c_int, vp, vp, vp]),

@@ -594,6 +594,40 @@ __global__ __launch_bounds__(1024) void k_best_record(int B, const double* __res
     for (int e = threadIdx.x; e < xlen; e += 1024) record[2 + e] = none ? 0.0 : X[(size_t)win * xlen + e];
 }
 
+// Winner among `nrec` records of `reclen` doubles (value, index bits, payload): smallest value with
+// NaN counted as +inf, ties to the smallest index.
+__global__ __launch_bounds__(256) void k_select_record(int nrec, int reclen, const double* __restrict__ rec,
+                                                       double* __restrict__ out) {
+    __shared__ double sv[256];
+    __shared__ long long si[256];
+    __shared__ int sr[256];
+    double bv = INFINITY;
+    long long bi = LLONG_MAX;
+    int br = -1;
+    for (int r = threadIdx.x; r < nrec; r += 256) {
+        const double x = rec[(size_t)r * reclen];
+        const double v = (x != x) ? INFINITY : x;
+        const long long idx = reinterpret_cast<const long long*>(rec + (size_t)r * reclen)[1];
+        if (br < 0 || v < bv || (v == bv && idx < bi)) { bv = v; bi = idx; br = r; }
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi; sr[threadIdx.x] = br;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+            const double ov = sv[threadIdx.x + off];
+            const long long oi = si[threadIdx.x + off];
+            const int orr = sr[threadIdx.x + off];
+            const bool mine = sr[threadIdx.x] >= 0;
+            if (orr >= 0 && (!mine || ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))) {
+                sv[threadIdx.x] = ov; si[threadIdx.x] = oi; sr[threadIdx.x] = orr;
+            }
+        }
+        __syncthreads();
+    }
+    const int win = sr[0];
+    for (int e = threadIdx.x; e < reclen; e += 256) out[e] = win >= 0 ? rec[(size_t)win * reclen + e] : NAN;
+}
+
 // ------------------------------------------------------------------------------------------------
 static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
@@ -923,6 +957,13 @@ extern "C" int oei_argmin(int B, const double* value, long long index_base, doub
                           long long* best_index, void* stream) {
     if (B < 0 || !best_value || !best_index || (B > 0 && !value)) { oei_set_error("argmin: bad argument"); return OEI_ERR_ARG; }
     hipLaunchKernelGGL(k_argmin, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, value, index_base, best_value, best_index);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+extern "C" int oei_select_record(int nrec, int reclen, const double* records, double* out, void* stream) {
+    if (nrec < 1 || reclen < 2 || !records || !out) { oei_set_error("select_record: bad argument"); return OEI_ERR_ARG; }
+    hipLaunchKernelGGL(k_select_record, dim3(1), dim3(256), 0, (hipStream_t)stream, nrec, reclen, records, out);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

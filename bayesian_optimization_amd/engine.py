@@ -287,3 +287,14 @@ def best_record(value, X, index_base=0):
         check(lib.oei_best_record(B, _ptr(value), _ptr(X), xlen, int(index_base), _ptr(rec), _stream()),
               'oei_best_record')
     return rec
+
+
+def select_record(records):
+    """Winner of the gathered per-rank records [nrec, reclen] (device tensor): smallest value, NaN as
+    +inf, ties to the smallest index; one launch.  Returns the winning record [reclen]."""
+    records = records.contiguous()
+    nrec, reclen = int(records.shape[0]), int(records.shape[1])
+    out = torch.empty(reclen, dtype=torch.float64, device=records.device)
+    with torch.cuda.device(records.device):
+        check(lib.oei_select_record(nrec, reclen, _ptr(records), _ptr(out), _stream()), 'oei_select_record')
+    return out

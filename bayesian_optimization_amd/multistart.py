@@ -42,6 +42,10 @@ def select_best(rec, group=None):
         allrec = flat.reshape(world, rec.numel()).to(rec.device)
     else:
         allrec = rec.reshape(1, -1)
+    if allrec.is_cuda:                      # one launch on the device
+        from . import engine
+        row = engine.select_record(allrec)
+        return row[0], row[1:2].view(torch.int64).reshape(()), row[2:]
     values = allrec[:, 0]
     indices = allrec[:, 1].contiguous().view(torch.int64)
     # NaN values never win; ties -> lowest global index

@@ -193,6 +193,13 @@ int oei_argmin(int B, const double* value, long long index_base,
 int oei_best_record(int B, const double* value, const double* X, int xlen, long long index_base,
                     double* record, void* stream);
 
+/* Selection among the gathered records of all ranks (the step after the all-gather; the reference
+ * keeps the best start of its sequential loop at bo.py:157-161): records device double[nrec, reclen]
+ * laid out as oei_best_record writes them -> out device double[reclen] = the record with the
+ * smallest value, NaN counting as +inf and ties going to the smallest index (so every rank count
+ * selects the same start).  One launch in place of a dozen small tensor operations. */
+int oei_select_record(int nrec, int reclen, const double* records, double* out, void* stream);
+
 /* ---- batched objective of the hyper-parameter fit ------------------------------------------------
  * bo.py:194-221 restarts gpflow's optimize() `model_restarts` times on the same data; the restarts
  * are independent, so R trial parameter vectors are evaluated in one pass (batch item z owns one

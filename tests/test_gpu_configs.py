@@ -177,3 +177,28 @@ def test_cfg4_launcher_two_ranks_one_gpu(cuda):
     assert two['best']['index'] == one['best']['index']
     assert two['best']['value'] == one['best']['value']
     assert two['best']['x_sha1'] == one['best']['x_sha1']
+
+
+def test_select_record_matches_the_tensor_statement(cuda):
+    """The fused cross-rank selection against the torch statement of the same rule (CPU path of
+    multistart.select_best): NaN as +inf, ties to the smallest index, the winner's row verbatim."""
+    from bayesian_optimization_amd import engine
+    rng = np.random.RandomState(11)
+    for nrec in (1, 2, 8, 300):
+        for case in range(4):
+            rec = rng.standard_normal((nrec, 2 + 120))
+            idx = rng.permutation(10 * nrec)[:nrec].astype(np.int64)
+            if case == 1 and nrec > 1:
+                rec[:, 0] = rec[0, 0]                       # all tied: the smallest index wins
+            if case == 2:
+                rec[rng.rand(nrec) < 0.5, 0] = np.nan
+            if case == 3:
+                rec[:, 0] = np.nan                          # nothing finite
+            rec[:, 1] = idx.view(np.float64)
+            t = torch.as_tensor(rec)
+            # torch statement on the CPU
+            values = torch.where(torch.isnan(t[:, 0]), torch.full_like(t[:, 0], float('inf')), t[:, 0])
+            cand = torch.where(values == values.min(), torch.as_tensor(idx), torch.full((nrec,), torch.iinfo(torch.int64).max))
+            win = int(torch.argmin(cand))
+            out = engine.select_record(t.to(cuda)).cpu()
+            assert out.numpy().tobytes() == t[win].numpy().tobytes()
