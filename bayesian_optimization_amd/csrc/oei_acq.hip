@@ -258,6 +258,7 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
                                              const double* __restrict__ v,
                                              double* __restrict__ omega) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     SdpWork w;
     sdp_carve(w, sm, q, false);
     lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, Q == 0 ? acq_stage_doubles(q) : 0, false);
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
                                               double* __restrict__ start_out,
                                               int* __restrict__ iters_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     SdpWork w;
     sdp_carve(w, sm, q, false);
     lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, Q == 0 ? acq_stage_doubles(q) : 0, false);
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(T) void k_grad(KernParams kp, int n, int npad, int 
                                             const double* __restrict__ M11_in,
                                             double* __restrict__ grad, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     const int d = kp.d, dp = d + 1, dl = (d + 1) | 1;
     lds_f64* xq = (lds_f64*)sm;               // [q][d]
     lds_f64* M11 = xq + q * d;                // [q][q]
@@ -464,6 +467,7 @@ __global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nr
                                                  const double* __restrict__ M11_in,
                                                  double* __restrict__ grad, int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     constexpr int T = 64;
     const int d = kp.d, dp = d + 1;
     lds_f64* xq = (lds_f64*)sm;               // [q][d]

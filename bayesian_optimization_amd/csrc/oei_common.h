@@ -75,6 +75,19 @@ struct oei_model {
     int n_cu;         // compute units of the device
 };
 
+// Diagnostic build (make poison, -DOEI_POISON_LDS): every kernel with dynamic LDS first fills it
+// with NaN, so that a result that depends on what an earlier kernel left in LDS shows up as NaN
+// (or as a status) in the test suite instead of once in a long sweep.  The size is the
+// hidden_dynamic_lds_size kernel argument (code object v5: byte 120 of the implicit arguments).
+#ifdef OEI_POISON_LDS
+#define OEI_LDS_POISON(sm) do { \
+        const unsigned n_ = ((const unsigned*)__builtin_amdgcn_implicitarg_ptr())[30] / 8u; \
+        for (unsigned i_ = threadIdx.x; i_ < n_; i_ += blockDim.x) (sm)[i_] = __longlong_as_double(0x7ff8000000000000LL); \
+        __syncthreads(); } while (0)
+#else
+#define OEI_LDS_POISON(sm)
+#endif
+
 // ---- device helpers ---------------------------------------------------------------------------
 
 // kappa(t) and (optionally) its first and second derivatives with respect to t = r2.

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __res
                                               double* __restrict__ out1, int q,
                                               int* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     const int d = kp.d;
     double* Xs = sm;                 // [64][d]
     double* Qs = sm + 64 * d;        // [GR_ROWS][d]
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void k_gram_ext(KernParams kp, const double* _
                                                   const double* __restrict__ Xq, int q, int RP,
                                                   double* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     const int d = kp.d, dp = d + 1;
     double* Xs = sm;                 // [64][d]
     double* Qs = sm + 64 * d;        // [GR_ROWS][d]

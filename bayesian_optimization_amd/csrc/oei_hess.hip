@@ -24,6 +24,7 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
                                                double* __restrict__ dM, double* __restrict__ dY,
                                                int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     SdpWork w;
     sdp_carve(w, sm, q, true);
     const int VL = sdp_vlen(q), LD = w.LD, k_ = q + 1;
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(T) void k_domega(KernParams kp, int q, int RP,
                                               const double* __restrict__ G,
                                               double* __restrict__ domega) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     const int d = kp.d, dp = d + 1, qd = q * d, k_ = q + 1, vrow = q * dp;
     lds_f64* xq = (lds_f64*)sm;          // [q*d]
     lds_f64* mu = xq + qd;               // [q]
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
                                                  double* tabs,
                                                  double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     const int VL = sdp_vlen(q), LD = sdp_ld(q), ML = q * LD, d = kp.d, dp = d + 1, qd = q * d;
     SdpWork w;
     w.q = q; w.LD = LD;
@@ -495,10 +498,11 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         if (sdp_newton_dir<T, 0>(w)) st = 2;          // reads U from w.X; w.S (Lc) is free afterwards
     }
     if (st) {
-        if (slice == 0) {
-            for (size_t e = tid; e < (size_t)qd * qd; e += T) Hb[e] = NAN;
-            if (tid == 0 && status) status[b] = 2;
-        }
+        // every slice answers for its own rows: the slices repeat the same solve, but one that
+        // breaks down alone must not leave its rows unwritten behind a status of 0
+        for (int al = slice; al < qd; al += nslice)
+            for (int e = tid; e < qd; e += T) Hb[(size_t)al * qd + e] = NAN;
+        if (tid == 0 && status) atomicMax(status + b, 2);
         return;
     }
     __syncthreads();
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         hess_contract(tid, T, kp, q, RP, a, l, w.X, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
                       (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
     }
-    if (slice == 0 && tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
+    if (slice == 0 && tid == 0 && status && sdp_status) atomicMax(status + b, sdp_status[b]);   // status[] starts at 0
 }
 
 // ---- register-path sizes (q <= 32): the same work in two kernels ---------------------------------
@@ -552,6 +556,7 @@ __global__ __launch_bounds__(T) void k_hess_prep(KernParams kp, double noise, do
                                                  double* __restrict__ state,
                                                  int* __restrict__ stflag) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     SdpWork w;
     sdp_carve(w, sm, q, true);
     const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d;
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
                                                  const int* __restrict__ sdp_status,
                                                  double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     constexpr int NW = T / 64;
     const int q = QE > 0 ? QE : q_arg;           // QE > 0: instance for exactly this q
     const int VL = sdp_vlen(q), LD = sdp_ld(q), ML = q * LD, d = kp.d, qd = q * d;
@@ -844,6 +850,7 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
 #undef LAUNCH_DIRS
         } else {
             double* tabs = reinterpret_cast<double*>(stb + ((Bc + 1) & ~1));
+            if (sc) OEI_HIP_CHECK(hipMemsetAsync(sc, 0, (size_t)Bc * sizeof(int), st));     // the slices raise it
             if ((rc = set_lds_attr((k_hess_wide<256>), lds))) return rc;
             hipLaunchKernelGGL((k_hess_wide<256>), dim3(Bc, nslice < qd ? nslice : qd), dim3(256), lds, st, m->kp, m->noise, m->fmin, m->n, npad, q, RP, m->X, m->alpha, Xc, m->hs, Wb, p_buf, M11_buf, stb, tabs, Hc, sc);
         }

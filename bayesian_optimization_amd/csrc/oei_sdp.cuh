@@ -1096,8 +1096,9 @@ __device__ __forceinline__ void sdp_item_z_wide(const SdpWork w, int LD, int e, 
 }
 
 // z^T K' z with K'(b, a), a > b, at Kt[b * LD + a]: row b is walked in groups of 16 contiguous
-// entries whose reads are issued together.  A group may run past column q - 1 into the following
-// row (or the matrix behind w.H): whatever finite numbers sit there meet the zeros of z.
+// entries whose reads are issued together.  A group may run past column q - 1 into the padding
+// column, the following row or the matrix behind w.H: the numbers there meet the zeros of z (the
+// caller clears the padding columns, which nothing else ever writes).
 template <int QM>
 __device__ __forceinline__ double sdp_quadform_wide(const double (&z)[QM], const SdpWork w, int LD, int q) {
     double tot = 0.0;
@@ -1234,6 +1235,13 @@ __device__ int sdp_newton_dir_wide(const SdpWork w) {
             const double sa = w.sq[a], sb = w.sq[b];
             w.H[b * LD + a] = sa * sb * sdp_rcp(sa + sb);
         }
+    }
+    // The walks over K' read whole groups of 16 entries and meet the zeros of z past column q - 1:
+    // in the padding column of the matrix (even q), in the following row and, for small q, in the
+    // first rows of the matrix behind w.H (w.S).  Rows hold numbers; the padding columns hold
+    // whatever the previous kernel left in LDS, and 0 * (NaN or Inf bits) is NaN: clear them.
+    if (LD > q) {
+        for (int i = tid; i < q; i += T) { w.H[i * LD + q] = 0.0; w.S[i * LD + q] = 0.0; }
     }
     __syncthreads();
     {

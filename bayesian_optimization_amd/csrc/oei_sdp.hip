@@ -9,6 +9,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_sdp_omega(int q, const 
                                                  double* __restrict__ Y, int* __restrict__ status,
                                                  int* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
     SdpWork w;
     sdp_carve(w, sm, q, false);
     lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, false);  // [q]

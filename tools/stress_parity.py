@@ -1,7 +1,9 @@
 """Randomised parity sweep (diagnostic, not part of the test suite): random shapes, kernels and
 hyper-parameters through the C ABI; value and gradient against the CPU restatement and the KKT
 certificate, the Hessian against central differences of the device gradient.
-Usage: python tools/stress_parity.py [seconds] [seed]"""
+Usage: python tools/stress_parity.py [seconds] [seed] [first case] [last case]
+(cases before the first only draw their random numbers, so a stretch of an earlier sweep can be
+re-run: what a call leaves behind in LDS and in freed buffers is part of the next call's input)"""
 import os
 import sys
 import time
@@ -15,11 +17,13 @@ from bayesian_optimization_amd import DeviceGP, sdp_batched          # noqa: E40
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+first_case = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+last_case = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 30
 t_end = time.time() + budget
 worst = dict(value=0.0, grad=0.0, cert=0.0, hess=0.0)
 fails = []
 case = 0
-while time.time() < t_end:
+while time.time() < t_end and case < last_case:
     case += 1
     q = int(rs.choice([1, 2, 3, 5, 8, 9, 13, 16, 17, 20, 24, 31, 32, 33, 41, 50, 64]))
     d = int(rs.randint(1, 13))
@@ -30,6 +34,11 @@ while time.time() < t_end:
     noise = float(10.0 ** rs.uniform(-6, -2))
     B = int(rs.choice([1, 2, 5]))
     tag = 'case %d: q=%d d=%d n=%d kind=%d fm=%d ls=%.2f noise=%.1e B=%d' % (case, q, d, n, kind, fm, ls, noise, B)
+    if case < first_case:                    # keep the random stream in step, no GPU work
+        rs.uniform(-.5, .5, (B, q, d))
+        if q * d <= 400:
+            rs.randn(B, q * d)
+        continue
     om = hart6.make_model(n, d=d, train_seed=case, kind=kind, floor_mode=fm, lengthscale=ls, noise=noise)
     dm = DeviceGP(om.X, om.y, kind, om.kernel.variance, om.kernel.lengthscales, om.noise, floor_mode=om.kernel.floor_mode)
     Xs = rs.uniform(-.5, .5, (B, q, d))
