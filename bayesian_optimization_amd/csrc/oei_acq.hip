@@ -884,6 +884,7 @@ extern "C" int oei_value_grad_batched(oei_model* m, int B, int q, const double* 
     const size_t rows_pad = round_up((size_t)B * q, 64);
     if ((rc = oei_ws_reserve(m, rows_pad, value_grad_aux_doubles(m, B, q) * sizeof(double)))) return rc;
     if ((rc = oei_ws2_reserve(m, rows_pad))) return rc;
+    OEI_SCRATCH_POISON(m, (hipStream_t)stream);
     return value_grad_auto(m, B, q, X, value, grad, status, flags, (hipStream_t)stream);
 }
 

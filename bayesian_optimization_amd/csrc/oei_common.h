@@ -84,8 +84,16 @@ struct oei_model {
         const unsigned n_ = ((const unsigned*)__builtin_amdgcn_implicitarg_ptr())[30] / 8u; \
         for (unsigned i_ = threadIdx.x; i_ < n_; i_ += blockDim.x) (sm)[i_] = __longlong_as_double(0x7ff8000000000000LL); \
         __syncthreads(); } while (0)
+// the same build fills the handle's scratch buffers with NaN bytes before a call uses them
+#define OEI_SCRATCH_POISON(m, st) do { \
+        if ((m)->ws0) hipMemsetAsync((m)->ws0, 0xFF, (m)->ws_rows * (size_t)(m)->npad * sizeof(double), st); \
+        if ((m)->ws1) hipMemsetAsync((m)->ws1, 0xFF, (m)->ws_rows * (size_t)(m)->npad * sizeof(double), st); \
+        if ((m)->ws2) hipMemsetAsync((m)->ws2, 0xFF, (m)->ws2_rows * (size_t)(m)->npad * sizeof(double), st); \
+        if ((m)->aux) hipMemsetAsync((m)->aux, 0xFF, (m)->aux_bytes, st); \
+        if ((m)->hs) hipMemsetAsync((m)->hs, 0xFF, (m)->hs_bytes, st); } while (0)
 #else
 #define OEI_LDS_POISON(sm)
+#define OEI_SCRATCH_POISON(m, st)
 #endif
 
 // ---- device helpers ---------------------------------------------------------------------------

@@ -746,6 +746,7 @@ static int hess_front(oei_model* m, int Bc, int q, const double* X, int RP, size
     if (rc) return rc;
     const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
     if ((rc = hs_reserve(m, gbytes + extra_bytes))) return rc;
+    OEI_SCRATCH_POISON(m, st);
     if ((rc = oei_launch_gram_ext(m, X, Bc, q, RP, m->ws0, st))) return rc;
     if ((rc = oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows, m->npad, 1, st))) return rc;
     return oei_launch_gram_blk(m->ws1, m->hs, Bc, RP, m->npad, st);
