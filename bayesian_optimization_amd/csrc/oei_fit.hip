@@ -311,6 +311,12 @@ extern "C" int oei_fit_create(oei_fit** out, int n, int d, const double* X_train
         OEI_HIP_CHECK(hipMalloc(&f->part, R * n * (2 + d) * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&f->val, R * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&f->flag, R * sizeof(int)));
+#ifdef OEI_POISON_LDS      // test variant: see oei_model_create
+        hipMemset(f->L, 0xFF, R * nn); hipMemset(f->Linv, 0xFF, R * nn); hipMemset(f->LinvT, 0xFF, R * nn);
+        hipMemset(f->Kinv, 0xFF, R * nn); hipMemset(f->Dinv, 0xFF, R * npad * TB * sizeof(double));
+        hipMemset(f->tmp, 0xFF, R * npad * TB * sizeof(double)); hipMemset(f->v, 0xFF, R * npad * sizeof(double));
+        hipMemset(f->alpha, 0xFF, R * npad * sizeof(double)); hipMemset(f->part, 0xFF, R * n * (2 + d) * sizeof(double));
+#endif
         OEI_HIP_CHECK(hipMemset(f->X, 0, npad * d * sizeof(double)));
         OEI_HIP_CHECK(hipMemset(f->y, 0, npad * sizeof(double)));
         OEI_HIP_CHECK(hipMemcpy(f->X, X_train, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice));

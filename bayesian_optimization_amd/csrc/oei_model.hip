@@ -171,6 +171,11 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
         OEI_HIP_CHECK(hipMalloc(&m->ftmp, (size_t)npad * TB * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&m->dscal, 2 * sizeof(double)));
         OEI_HIP_CHECK(hipMalloc(&m->dflag, sizeof(int)));
+#ifdef OEI_POISON_LDS      // test variant: what the factorisation does not write is NaN, not the zeros of a fresh allocation
+        hipMemset(m->L, 0xFF, nn); hipMemset(m->Linv, 0xFF, nn); hipMemset(m->LinvT, 0xFF, nn);
+        hipMemset(m->v, 0xFF, npad * sizeof(double)); hipMemset(m->alpha, 0xFF, npad * sizeof(double));
+        hipMemset(m->Dinv, 0xFF, (size_t)npad * TB * sizeof(double)); hipMemset(m->ftmp, 0xFF, (size_t)npad * TB * sizeof(double));
+#endif
         OEI_HIP_CHECK(hipMemset(m->X, 0, (size_t)npad * d * sizeof(double)));
         OEI_HIP_CHECK(hipMemset(m->y, 0, npad * sizeof(double)));
         OEI_HIP_CHECK(hipMemcpy(m->X, X_train, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice));
