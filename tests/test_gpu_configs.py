@@ -179,6 +179,28 @@ def test_cfg4_launcher_two_ranks_one_gpu(cuda):
     assert two['best']['x_sha1'] == one['best']['x_sha1']
 
 
+def test_forced_pieces_and_kernel_timer(cuda):
+    """The diagnostic piece count of oei_set_pipelining at sizes where pieces are ragged (bitwise the
+    one-stream results), and the timer on the solver kernel's own dispatch: positive and not longer
+    than the event interval around the kernel."""
+    om, dm = _mk(70)
+    for B, q in ((37, 20), (100, 7), (5, 32)):
+        Xd = torch.as_tensor(np.random.RandomState(B).uniform(-.5, .5, (B, q, 6)), device=cuda)
+        dm.set_pipelining(0)
+        ref = dm.value_grad(Xd)
+        for pieces in (2, 3, 5):
+            dm.set_pipelining(pieces)
+            out = dm.value_grad(Xd)
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b), (B, q, pieces)
+    dm.set_pipelining(1)
+    dm.set_profiling(True)
+    dm.value_grad(Xd)
+    stage, kernel = dm.stage_times_ms(), dm.solver_kernel_ms()
+    dm.set_profiling(False)
+    assert 0.0 < kernel <= stage[2] * 1.05 + 0.01
+
+
 def test_select_record_matches_the_tensor_statement(cuda):
     """The fused cross-rank selection against the torch statement of the same rule (CPU path of
     multistart.select_best): NaN as +inf, ties to the smallest index, the winner's row verbatim."""
