@@ -369,7 +369,9 @@ __device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, con
 
 // Row (a,l) of the Hessian from the direction's dN (q x LD), w1, w2, dN mu: the contraction with
 // every dOmega_(b,m) plus d2<Omega,M>/dx2 at fixed M.  `nth` threads numbered `tid` share the row.
-template <typename MP, typename TP>
+// WVFORM: `dN` holds Y = U Z and `DS` the table WV[b,m] = U^T v'_(b,m) in place of dSigma/dx, so
+// that <dN, dS_(b,m)> = 2 (dN v')_b = 2 Y[b,:] . WV[b,m].
+template <bool WVFORM = false, typename MP, typename TP>
 __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams& kp, int q, int RP,
                                               int a, int l, const lds_f64* dN, int LD,
                                               TP DS, const lds_f64* dmuT,
@@ -386,8 +388,14 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
         // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
         double acc = 0.0;
         const auto dsrow = DS + (size_t)bm * q;
+        if constexpr (WVFORM) {
 #pragma unroll 4
-        for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
+            for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c];
+            acc *= 2.0;
+        } else {
+#pragma unroll 4
+            for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
+        }
         double P = -acc + 2.0 * dmuT[bm] * (w1[bb] + w2[bb] - dNmu[bb]);
         // d2<Omega,M>/dx2 at fixed M
         // T_al . T_bm: the first two passes may have been fetched ahead by the caller
@@ -612,8 +620,8 @@ __global__ __launch_bounds__(T) void k_hess_prep(KernParams kp, double noise, do
 
 #define HESS_WAVE_NVEC 9      // dmu dp rd t2 dc w1 w2 dNmu wv
 __host__ __device__ inline size_t hess_dirs_shared_doubles(int q, int d) {
-    // U R L phiS phiD | rc sq rp c t1 mu p | xq | tab | dmuT | k1s k2s M11 | Dg
-    return (size_t)5 * q * sdp_ld(q) + (size_t)7 * sdp_vlen(q) + (size_t)q * d + hess_tab_doubles(q, d) +
+    // U R L phiS phiD | rc sq rp c t1 mu p utc utmu | xq | tab | dmuT | k1s k2s M11 | Dg
+    return (size_t)5 * q * sdp_ld(q) + (size_t)9 * sdp_vlen(q) + (size_t)q * d + hess_tab_doubles(q, d) +
            (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
 }
 __host__ __device__ inline size_t hess_dirs_wave_doubles(int q) {
@@ -655,8 +663,10 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     lds_f64* rc = phiD + ML;      lds_f64* sq = rc + VL;      lds_f64* rp = sq + VL;
     lds_f64* cv = rp + VL;        lds_f64* t1 = cv + VL;      lds_f64* mu = t1 + VL;
     lds_f64* pv = mu + VL;
-    lds_f64* xq = pv + VL;                       // [q*d]
-    lds_f64* tab = xq + qd;                      // DS [q*d*q], first used as chunk staging
+    lds_f64* utc = pv + VL;                      // U^T c
+    lds_f64* utmu = utc + VL;                    // U^T mu
+    lds_f64* xq = utmu + VL;                     // [q*d]
+    lds_f64* tab = xq + qd;                      // DS [q*d*q] (then U^T v' of every direction), first used as chunk staging
     lds_f64* dmuT = tab + hess_tab_doubles(q, d);
     lds_f64* k1s = dmuT + qd;
     lds_f64* k2s = k1s + q * q;
@@ -683,6 +693,25 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         phiS[a * LD + c] = -0.5 * sdp_rcp(sa * sc * (sa + sc));
         phiD[a * LD + c] = 0.5 * sdp_rcp(sa + sc);
     }
+    // Row (b,m) of the table becomes U^T v'_(b,m) (v'_j = dSigma_bj/dx_bm, j != b; half of it at
+    // j = b), in place: it is both the direction's own input and what the contraction of every
+    // other direction meets, so no direction forms dN = Y U^T.  A wave takes every NW-th row; lane t
+    // reads the whole row and column t of U, and the row is overwritten once all lanes have read it.
+    for (int bm = wave; bm < qd; bm += NW) {
+        const int bb = bm / d;
+        lds_f64* row = tab + (size_t)bm * q;
+        double acc = 0.0;
+        if (lane < q) {
+#pragma unroll 4
+            for (int c = 0; c < q; ++c) acc = fma(U[c * LD + lane], row[c] * (c == bb ? 0.5 : 1.0), acc);
+        }
+        sens_sync<true>();
+        if (lane < q) row[lane] = acc;
+    }
+    if (tid < q) {
+        utc[tid] = lds_dot(U + tid, LD, cv, 1, q);
+        utmu[tid] = lds_dot(U + tid, LD, mu, 1, q);
+    }
     __syncthreads();
 
     // ---- directions: wave `wave` of slice s takes al = wave + NW s, then every NW * nslice-th ----
@@ -708,10 +737,10 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
             ttpre[u] = gsym(Gb, RP, a * (d + 1) + 1 + l, bb * (d + 1) + 1 + m2);
         }
         if (lane < q) sv.dmu[lane] = (lane == a) ? dmuT[al] : 0.0;
-        sens_direction<64, true, true, QE>(w, sv, SensDir{a, DS + (size_t)al * q, wvec, phiS, phiD});
-        if (lane < q) dNmu[lane] = lds_dot(w.X + lane * LD, 1, mu, 1, q);
+        sens_direction<64, true, true, QE, true>(w, sv, SensDir{a, nullptr, tab + (size_t)al * q, phiS, phiD, utc});
+        if (lane < q) dNmu[lane] = lds_dot(w.V + lane * LD, 1, utmu, 1, q);      // dN mu = Y (U^T mu)
         sens_sync<true>();
-        hess_contract(lane, 64, kp, q, RP, a, l, w.X, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, (const lds_f64*)M11, xq,
+        hess_contract<true>(lane, 64, kp, q, RP, a, l, w.V, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, (const lds_f64*)M11, xq,
                       (const lds_f64*)k1s, (const lds_f64*)k2s, (const lds_f64*)Dg, Hb, ttpre);
     }
     // a solve that stopped at the Newton iteration limit (status 1) still gets its Hessian

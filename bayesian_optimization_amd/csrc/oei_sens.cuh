@@ -210,9 +210,10 @@ struct SensDir {
     // RANK2 form: dS = e_a v'^T + v' e_a^T with v'_j = vrow[j] (j != a), v'_a = vrow[a] / 2
     int a;
     const lds_f64* vrow;
-    lds_f64* wv;                 // [q] scratch for U^T v'
+    lds_f64* wv;                 // [q] scratch for U^T v' (YFORM: the caller's U^T v', read only)
     // phiS[a][b] = -1 / (2 sq_a sq_b (sq_a + sq_b)),  phiD[a][b] = 1 / (2 (sq_a + sq_b)); or null
     const lds_f64 *phiS, *phiD;
+    const lds_f64* utc = nullptr;   // YFORM: U^T c
 };
 
 // One direction.  In: sv.dmu and dS -- a symmetric matrix in w.X, or in the RANK2 form of
@@ -223,7 +224,11 @@ struct SensDir {
 // RANK2 form w.X is not an input and may be the same buffer as w.Kt (Z is then overwritten by dN).
 // QE > 0: q is known at compile time (q == QE), which turns the index arithmetic of the passes and
 // the strides of the products into constants.
-template <int T, bool WAVE, bool RANK2, int QE = 0>
+// YFORM (with RANK2): the caller needs dN only in products dN x with vectors x whose U^T x it
+// already holds (the Hessian contraction: x = v' of every direction, c, mu), so the direction
+// stops at Y = U Z (in w.V; dN x = Y (U^T x)) and leaves out the product dN = Y U^T; its own
+// U^T v' comes in through sd.wv.  Out: Y in w.V, sv.w1 = N dc, sv.w2 = dN c = Y (U^T c), sv.dp.
+template <int T, bool WAVE, bool RANK2, int QE = 0, bool YFORM = false>
 __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec sv, const SensDir sd) {
     constexpr int TT = WAVE ? 64 : T;
     const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
@@ -235,11 +240,13 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     sens_sync<WAVE>();
     if constexpr (RANK2) {
         // U^T dS U = u wv^T + wv u^T with u = row a of U, wv = U^T v'
-        if (tid < q) {
-            const double acc = lds_dot(U + tid, LD, sd.vrow, 1, q);
-            sd.wv[tid] = acc - 0.5 * U[sd.a * LD + tid] * sd.vrow[sd.a];
+        if constexpr (!YFORM) {
+            if (tid < q) {
+                const double acc = lds_dot(U + tid, LD, sd.vrow, 1, q);
+                sd.wv[tid] = acc - 0.5 * U[sd.a * LD + tid] * sd.vrow[sd.a];
+            }
+            sens_sync<WAVE>();
         }
-        sens_sync<WAVE>();
         const lds_f64* ua = U + sd.a * LD;
         for (int e = tid; e < q * q; e += TT) {            // ZS
             const int a = e / q, b = e - a * q;
@@ -313,10 +320,16 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
         Tc[a * LD + b] += acc * (sd.phiD ? sd.phiD[a * LD + b] : 0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
     sens_sync<WAVE>();
-    sens_mm<T, WAVE, false, true, false>(tid, q, LD, Tc, U, Tb);             // Tb = Z U^T
-    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);         // Z t1
-    sens_sync<WAVE>();
-    sens_mm<T, WAVE, false, false, false>(tid, q, LD, U, Tb, Ta);            // Ta = dN = U Z U^T
+    if constexpr (YFORM) {
+        sens_mm<T, WAVE, false, false, false>(tid, q, LD, U, Tc, Tb);        // Tb = Y = U Z
+        if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);     // Z t1
+        sens_sync<WAVE>();
+    } else {
+        sens_mm<T, WAVE, false, true, false>(tid, q, LD, Tc, U, Tb);         // Tb = Z U^T
+        if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);     // Z t1
+        sens_sync<WAVE>();
+        sens_mm<T, WAVE, false, false, false>(tid, q, LD, U, Tb, Ta);        // Ta = dN = U Z U^T
+    }
     // dc = dmu + (dB p + B dp)/2 = dmu - 2 Rs (Z t1) + R (sq o rd)
     if (tid < q) sv.dc[tid] = sv.dmu[tid] + lds_dot_rs(w.R + tid * LD, w.sq, sv.rd, 1, sv.t2, q);
     sens_sync<WAVE>();
@@ -324,7 +337,8 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     sens_sync<WAVE>();
     if (tid < q) {
         sv.w1[tid] = 0.5 * lds_dot(U + tid * LD, 1, sv.t2, 1, q);      // N dc
-        sv.w2[tid] = lds_dot(Ta + tid * LD, 1, sv.c, 1, q);            // dN c
+        sv.w2[tid] = YFORM ? lds_dot(Tb + tid * LD, 1, sd.utc, 1, q)    // dN c = Y (U^T c)
+                           : lds_dot(Ta + tid * LD, 1, sv.c, 1, q);    // dN c
     }
     sens_sync<WAVE>();
     double dnu = 0.0;
