@@ -424,8 +424,8 @@ __host__ __device__ inline size_t hess_wide_table_doubles(int q, int d) {
     return (size_t)q * d * q + 2 * (size_t)q * q + (size_t)q * d * d;      // DS | k1s | k2s | Dg
 }
 __host__ __device__ inline size_t hess_wide_lds_doubles(int q, int d) {
-    // H S X V | 15 solver vectors + 8 scalars | mu, 9 sensitivity vectors, dNmu, vr, wv, scl | xq | dmuT
-    return (size_t)4 * q * sdp_ld(q) + (size_t)(SDP_NVEC + 1 + SENS_NVEC + 4) * sdp_vlen(q) + 8 + 2 * (size_t)q * d;
+    // H S X V | 15 solver vectors + 8 scalars | mu, 9 sensitivity vectors, dNmu, utc, utmu, wv, scl | xq | dmuT
+    return (size_t)4 * q * sdp_ld(q) + (size_t)(SDP_NVEC + 1 + SENS_NVEC + 5) * sdp_vlen(q) + 8 + 2 * (size_t)q * d;
 }
 
 template <int T>
@@ -458,7 +458,8 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     SensVec sv;
     sens_carve(sv, ptr, q); ptr += SENS_NVEC * VL;
     lds_f64* dNmu = ptr; ptr += VL;
-    lds_f64* vr = ptr; ptr += VL;
+    lds_f64* utc = ptr; ptr += VL;
+    lds_f64* utmu = ptr; ptr += VL;
     lds_f64* wv = ptr; ptr += VL;
     lds_f64* scl = ptr; ptr += VL;
     lds_f64* xq = ptr; ptr += qd;
@@ -526,6 +527,28 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         w.rc[tid] = 1.0 / w.H[tid * LD + tid];
     }
     __syncthreads();
+    // Row (b,m) of the dSigma/dx table becomes U^T v'_(b,m) (half weight at j = b), in place: the
+    // direction's own input and what the contraction of every other direction meets (see
+    // k_hess_dirs).  A wave per row, lane t = entry t; the row is overwritten after all lanes read it.
+    if (tid < q) {
+        utc[tid] = lds_dot(w.S + tid, LD, sv.c, 1, q);
+        utmu[tid] = lds_dot(w.S + tid, LD, mu, 1, q);
+    }
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int bm = wave; bm < qd; bm += T / 64) {
+            const int bb = bm / d;
+            double* row = DS + (size_t)bm * q;
+            double acc = 0.0;
+            if (lane < q) {
+#pragma unroll 4
+                for (int c = 0; c < q; ++c) acc = fma(w.S[c * LD + lane], row[c] * (c == bb ? 0.5 : 1.0), acc);
+            }
+            sdp_wave_sync();
+            if (lane < q) row[lane] = acc;
+        }
+    }
+    __syncthreads();
 
     // ---- one sensitivity solve per direction, fused with the contraction ------------------------
     for (int al = slice; al < qd; al += nslice) {
@@ -533,13 +556,13 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         __syncthreads();
         if (tid < q) {
             sv.dmu[tid] = (tid == a) ? dmuT[al] : 0.0;
-            vr[tid] = DS[(size_t)al * q + tid];
+            wv[tid] = DS[(size_t)al * q + tid];
         }
-        sens_direction_lean<T>(w, sv, a, vr, wv, scl);
-        if (tid < q) dNmu[tid] = lds_dot(w.X + tid * LD, 1, mu, 1, q);
+        sens_direction_lean<T>(w, sv, a, wv, scl, utc);
+        if (tid < q) dNmu[tid] = lds_dot(w.V + tid * LD, 1, utmu, 1, q);      // dN mu = Y (U^T mu)
         __syncthreads();
-        hess_contract(tid, T, kp, q, RP, a, l, w.X, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
-                      (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
+        hess_contract<true>(tid, T, kp, q, RP, a, l, w.V, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
+                            (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
     }
     if (slice == 0 && tid == 0 && status && sdp_status) atomicMax(status + b, sdp_status[b]);   // status[] starts at 0
 }

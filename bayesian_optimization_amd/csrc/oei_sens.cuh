@@ -353,22 +353,18 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
 //   ZS diag(sq) R^T = M1' diag(1/p) + (ZS t1) 1^T,
 //   R^T diag(dp) R  = U^T diag(dp / p^2) U + h rp^T + rp h^T + (sum dp) rp rp^T,  h = U^T (dp / p),
 //   rd = R^T dp = h + (sum dp) rp,   so  R^T dD R = U^T diag(dp / p^2) U - (sum dp) rp rp^T.
-// In: sv.dmu and the perturbation in rank-2 form dS = e_a v'^T + v' e_a^T, v'_j = vr[j] (j != a),
-// v'_a = vr[a] / 2 (vr in LDS).  Out: dN in w.X, sv.w1 = N dc, sv.w2 = dN c, sv.dp.
-// Needs w.rc = 1 / diag(L), w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1; wv and scl are [q] scratch.
+// In: sv.dmu and the perturbation in rank-2 form dS = e_a v'^T + v' e_a^T through wv = U^T v'
+// (in LDS; overwritten).  Like the YFORM of sens_direction it stops at Y = U Z: out Y in w.V,
+// sv.w1 = N dc, sv.w2 = dN c = Y utc (utc = U^T c), sv.dp.
+// Needs w.rc = 1 / diag(L), w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1; scl is [q] scratch.
 template <int T>
 __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensVec sv, int a_dir,
-                                                    const lds_f64* vr, lds_f64* wv, lds_f64* scl) {
+                                                    lds_f64* wv, lds_f64* scl, const lds_f64* utc) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const lds_f64* U = w.S;
     lds_f64* Tc = w.X;
     lds_f64* Tb = w.V;
-    __syncthreads();
-    if (tid < q) {
-        const double acc = lds_dot(U + tid, LD, vr, 1, q);
-        wv[tid] = acc - 0.5 * U[a_dir * LD + tid] * vr[a_dir];
-    }
     __syncthreads();
     {
         const lds_f64* ua = U + a_dir * LD;
@@ -431,10 +427,9 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         Tc[a * LD + b] += acc * (0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
     __syncthreads();
-    lds_mm<T, false, true, false>(q, LD, Tc, U, Tb);           // Tb = Z U^T
+    lds_mm<T, false, false, false>(q, LD, U, Tc, Tb);          // Tb = Y = U Z
     if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);        // Z t1
     __syncthreads();
-    lds_mm<T, false, false, false>(q, LD, U, Tb, Tc);          // dN = U Z U^T replaces Z
     if (tid < q) {
         // dc = dmu + sum_a R[i][a] sq[a] (rd[a] - 2 t2[a])
         const double ipi = w.ip[tid];
@@ -450,7 +445,7 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     __syncthreads();
     if (tid < q) {
         sv.w1[tid] = 0.5 * lds_dot(U + tid * LD, 1, wv, 1, q);          // N dc
-        sv.w2[tid] = lds_dot(Tc + tid * LD, 1, sv.c, 1, q);             // dN c
+        sv.w2[tid] = lds_dot(Tb + tid * LD, 1, utc, 1, q);              // dN c = Y (U^T c)
     }
     __syncthreads();
 }
