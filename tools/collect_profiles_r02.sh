@@ -18,6 +18,7 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-for
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --steps 5 --warmup 1 > $O/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/cfg3 -o cfg3 --output-format csv -- python3 tools/bench_cfg3.py > $O/cfg3.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/hess3 -o hess3 --output-format csv -- python3 tools/bench_hessian_cfg3.py > $O/hess3.log 2>&1 || exit 1
+timeout -k 10 100 python3 tools/bench_hessian_small.py > $O/hess_small.log 2>&1 || exit 1
 timeout -k 10 200 python3 tools/bench_model.py > $O/model.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/bench_lockstep.py > $O/lockstep.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/bench_fit.py > $O/fit.log 2>&1 || exit 1

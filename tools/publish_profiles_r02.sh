@@ -15,6 +15,7 @@ grep -v "$F" $O/cfg3.log > profiles/r02_cfg3.log
 grep -v "$F" $O/pipeline.log > profiles/r02_pipeline.log
 grep -v "$F" $O/hess3.log > profiles/r02_hess_cfg3.log
 grep -v "$F" $O/model.log > profiles/r02_model_create.log
+grep -v "$F" $O/hess_small.log > profiles/r02_hessian_small.log
 grep -v "$F" $O/lockstep.log > profiles/r02_lockstep.log
 grep -v "$F" $O/fit.log > profiles/r02_fit.log
 grep -v "$F" $O/phase_cycles.log > profiles/r02_phase_cycles.log
