@@ -68,9 +68,10 @@ def hessian_flops_model(q, d, n, npad, sdp_flops):
                 triangular GEMM with L^-1 (K range of a 64-column tile stops at its diagonal), then
                 the Gram matrix of the block (lower block triangle, n-length sums)
       solve     the SDP solve of the value+gradient path (`sdp_flops`) plus W = Z L^-1
-      dirs      q d directions: four q^3 products, about 12 q^2 for the vector passes and the two
-                triangular solves, and the contraction of the direction's row with every
-                dOmega_(b,m): q d (2 q + 30)
+      dirs      the table U^T v' of every direction (q d rows of q^2 multiply-adds), then q d
+                directions: three q^3 products (the direction stops at Y = U Z), about 12 q^2 for
+                the vector passes and the two triangular solves, and the contraction of the
+                direction's row with every dOmega_(b,m): q d (2 q + 30)
     """
     RP = -(-(q * (d + 1) + 1) // 64) * 64
     nt = npad // 64
@@ -78,7 +79,7 @@ def hessian_flops_model(q, d, n, npad, sdp_flops):
     front = RP * tri + (RP // 64) * (RP // 64 + 1) // 2 * 2 * 64 * 64 * npad
     solve = sdp_flops + q * tri
     qd = q * d
-    dirs = qd * (8 * q ** 3 + 12 * q * q) + qd * qd * (2 * q + 30)
+    dirs = qd * 2 * q * q + qd * (6 * q ** 3 + 12 * q * q) + qd * qd * (2 * q + 30)
     return front + solve + dirs
 
 
