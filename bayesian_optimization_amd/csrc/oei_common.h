@@ -155,7 +155,8 @@ int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const d
                       const double* start_in = nullptr, double* start_out = nullptr, int* iters = nullptr,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // G_b = E_b E_b^T (lower block-triangle of 64x64 tiles), E [B*RP, npad], G [B, RP, RP].
-int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st);
+// `used`: rows of a block that hold data (the others are zero rows whose products nothing reads; 0 = all).
+int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st, int used = 0);
 // C[r, j] = sum_k A[r, k] * Bm[j, k], all [*, npad] row-major; `lower` != 0 means Bm is lower
 // triangular (k <= j), else upper triangular (k >= j).
 // Fused W = Z L^-1 and gradient contraction; Gpart [npad / 64][nrows][d+1] partial sums.

@@ -520,10 +520,60 @@ int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, 
     return OEI_OK;
 }
 
+// The 64 x 64 tile when only the first 16 rows of the A panel hold data (the last row tile of a
+// block whose row count is just past a multiple of 64): the four waves share those 16 rows and
+// take one 16-column group each, a quarter of the matrix instructions per wave.  Rows 16..63 of the
+// output tile are not written (padding rows of the block, which nothing reads).
+__device__ __forceinline__ void gemm_tile_nt_strip16(const double* __restrict__ Ag0,
+                                                     const double* __restrict__ Bg0,
+                                                     double* __restrict__ Cg, int ld, int ldc,
+                                                     int kend, double* As, double* Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int srow = tid >> 2, scol = (tid & 3) * 4;
+    const double* Ag = Ag0 + (size_t)(srow & 15) * ld + scol;      // only 16 A rows are staged (four times over)
+    const double* Bg = Bg0 + (size_t)srow * ld + scol;
+    double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double2 a0, a1, b0, b1;
+    a0 = *reinterpret_cast<const double2*>(Ag);
+    a1 = *reinterpret_cast<const double2*>(Ag + 2);
+    b0 = *reinterpret_cast<const double2*>(Bg);
+    b1 = *reinterpret_cast<const double2*>(Bg + 2);
+    int buf = 0;
+    for (int k0 = 0; k0 < kend; k0 += GM_BK) {
+        double* as = As + buf * (GM_BM * GM_LDS);
+        double* bs = Bs + buf * (GM_BN * GM_LDS);
+        if (srow < 16) {
+            as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
+            as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
+        }
+        bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
+        bs[srow * GM_LDS + scol + 2] = b1.x; bs[srow * GM_LDS + scol + 3] = b1.y;
+        __syncthreads();
+        if (k0 + GM_BK < kend) {
+            a0 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK);
+            a1 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK + 2);
+            b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
+            b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
+        }
+        const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < GM_BK / 4; ++ks) {
+            const double av = as[li * GM_LDS + ks * 4 + lk];
+            const double bv = bs[(wave * 16 + li) * GM_LDS + ks * 4 + lk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Cg[(size_t)(rq + 4 * g) * ldc + wave * 16 + col] = acc[g];
+}
+
 // G_b = E_b E_b^T for every candidate: lower block-triangle of 64x64 tiles, tile index t of
-// blockIdx.y enumerates (I >= J).  E [B*RP, npad], G [B, RP, RP].
+// blockIdx.y enumerates (I >= J).  E [B*RP, npad], G [B, RP, RP].  `used`: rows of a block that
+// hold data (the rest are zero rows).
 __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
-                                                  double* __restrict__ G, int RP, int npad) {
+                                                  double* __restrict__ G, int RP, int npad, int used) {
     __shared__ __attribute__((aligned(16))) double As[2 * GM_BM * GM_LDS];
     __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
     const size_t b = blockIdx.x;
@@ -531,14 +581,18 @@ __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
     while ((I + 1) * (I + 2) / 2 <= t) ++I;
     const int J = t - I * (I + 1) / 2;
     const double* Eb = E + b * (size_t)RP * npad;
-    gemm_tile_nt(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad,
-                 G + b * (size_t)RP * RP + (size_t)I * 64 * RP + J * 64, npad, RP, 0, npad, As, Bs, 0);
+    double* Gt = G + b * (size_t)RP * RP + (size_t)I * 64 * RP + J * 64;
+    if (used - I * 64 <= 16)
+        gemm_tile_nt_strip16(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, npad, As, Bs);
+    else
+        gemm_tile_nt(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, 0, npad, As, Bs, 0);
 }
 
-int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st) {
+int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st, int used) {
     const int nt = RP / 64;
+    if (used <= 0 || used > RP) used = RP;
     dim3 grid((unsigned)B, nt * (nt + 1) / 2);
-    hipLaunchKernelGGL(k_gram_blk, grid, dim3(256), 0, st, E, G, RP, npad);
+    hipLaunchKernelGGL(k_gram_blk, grid, dim3(256), 0, st, E, G, RP, npad, used);
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

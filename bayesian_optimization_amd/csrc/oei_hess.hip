@@ -641,7 +641,7 @@ __global__ __launch_bounds__(T) void k_hess_prep(KernParams kp, double noise, do
     }
 }
 
-#define HESS_WAVE_NVEC 9      // dmu dp rd t2 dc w1 w2 dNmu wv
+#define HESS_WAVE_NVEC 8      // dmu dp rd t2 dc w1 w2 dNmu
 __host__ __device__ inline size_t hess_dirs_shared_doubles(int q, int d) {
     // U R L phiS phiD | rc sq rp c t1 mu p utc utmu | xq | tab | dmuT | k1s k2s M11 | Dg
     return (size_t)5 * q * sdp_ld(q) + (size_t)9 * sdp_vlen(q) + (size_t)q * d + hess_tab_doubles(q, d) +
@@ -747,7 +747,6 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     sv.dmu = wv0;            sv.dp = wv0 + VL;      sv.rd = wv0 + 2 * VL;  sv.t2 = wv0 + 3 * VL;
     sv.dc = wv0 + 4 * VL;    sv.w1 = wv0 + 5 * VL;  sv.w2 = wv0 + 6 * VL;
     lds_f64* dNmu = wv0 + 7 * VL;
-    lds_f64* wvec = wv0 + 8 * VL;
     sv.c = cv; sv.t1 = t1;
     for (int al = wave + NW * slice; al < qd; al += NW * nslice) {
         const int a = al / d, l = al - a * d;
@@ -801,7 +800,7 @@ static int hess_front(oei_model* m, int Bc, int q, const double* X, int RP, size
     OEI_SCRATCH_POISON(m, st);
     if ((rc = oei_launch_gram_ext(m, X, Bc, q, RP, m->ws0, st))) return rc;
     if ((rc = oei_launch_gemm_nt(m->ws0, m->Linv, m->ws1, rows, m->npad, 1, st))) return rc;
-    return oei_launch_gram_blk(m->ws1, m->hs, Bc, RP, m->npad, st);
+    return oei_launch_gram_blk(m->ws1, m->hs, Bc, RP, m->npad, st, q * (m->d + 1) + 1);
 }
 
 extern "C" int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* domega,
