@@ -349,6 +349,120 @@ __device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int
     __syncthreads();
 }
 
+// The same sums for a workgroup of NW = T / 64 waves with per-wave scratch (k_hess_dirs, d <= 15):
+// the second-moment part sum_k c2[a,k] (x_al - X_kl)(x_am - X_km) runs on the matrix pipe.  A wave
+// owns `na` = 16 / (d + 1) points a; row i = ia (d + 1) + r of its 16 x 16 tile is coordinate r of
+// point ia (r < d), or the row that sums c1 (r = d: left operand c1, right operand 1).  Per four
+// training points lane (i, kk) supplies c2[a,k] diff and diff (k = 4 s + kk), the same index
+// pattern on both sides, so one LDS read pair feeds both operands; the diagonal blocks of the tile
+// are the wanted sums, the off-diagonal blocks (products across points) are ignored.  The tile
+// accumulates over all training points in registers.  Chunk length: the multiple of four that
+// minimises kernel-evaluation passes over the workgroup.  What a thread's first staging element
+// and first evaluation read from global memory is fetched one chunk ahead, so that its latency
+// passes behind the previous chunk's work.  Leaves a barrier behind.
+template <int T>
+__device__ __forceinline__ void hess_dg_prepass_mfma(const KernParams& kp, int n, int npad, int q,
+                                                     const lds_f64* xq, const lds_f64* pv, lds_f64* tab,
+                                                     size_t tabsz, lds_f64* Dg, lds_f64* wscratch,
+                                                     const double* __restrict__ Xtrain,
+                                                     const double* __restrict__ alpha,
+                                                     const double* __restrict__ Wrows) {
+    constexpr int NW = T / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = kp.d, dl = (d + 1) | 1, dp = d + 1;
+    const int na = 16 / dp;                              // points per tile (d <= 15: >= 1)
+    const int li = lane & 15, kk = lane >> 4;
+    const int ia = li / dp, r = li - ia * dp;
+    const bool rowlive = ia < na;
+    const int per_pass = NW * na;
+    for (int a_lo = 0; a_lo < q; a_lo += per_pass) {
+        const int a_cnt = min(q - a_lo, per_pass);
+        int ch_max = (int)((tabsz - 2 * a_cnt) / (2 * a_cnt + dl));
+        ch_max = min(ch_max & ~3, 64);
+        int ch = 4, best = INT_MAX;
+        for (int c = 4; c <= ch_max; c += 4) {
+            const int chunks = (n + c - 1) / c, cost = chunks * (4 * ((a_cnt * c + T - 1) / T) + 1);
+            if (cost <= best) { best = cost; ch = c; }
+        }
+        lds_f64* c1 = tab;                        // [a_cnt][ch+1]  coef * 2 var kappa'
+        lds_f64* c2 = c1 + a_cnt * (ch + 1);      // [a_cnt][ch+1]  coef * 4 var kappa''
+        lds_f64* Xc = c2 + a_cnt * (ch + 1);      // [ch][dl]
+        const int at = wave * na + ia;            // this lane's point within the pass
+        const bool live = rowlive && at < a_cnt;
+        const int ac = live ? at : 0;
+        const double xa = (live && r < d) ? xq[(a_lo + ac) * d + r] : 0.0;
+        sens_double4 acc = (sens_double4){0.0, 0.0, 0.0, 0.0};
+        const int xk = tid / d, xl = tid - xk * d;              // staging element tid: training point, coordinate
+        const int ea = tid / ch, ek = tid - ea * ch;            // evaluation tid: point, training point
+        const bool xown = tid < ch * d, eown = tid < a_cnt * ch;
+        const double* wrow = Wrows + (size_t)(a_lo + (eown ? ea : 0)) * npad;
+        double nx = (xown && xk < n) ? Xtrain[(size_t)xk * d + xl] : 0.0;
+        double nal = (eown && ek < n) ? alpha[ek] : 0.0, nw = (eown && ek < n) ? wrow[ek] : 0.0;
+        for (int c0 = 0; c0 < n; c0 += ch) {
+            __syncthreads();
+            if (xown) Xc[xk * dl + xl] = nx;
+            for (int e = tid + T; e < ch * d; e += T) {
+                const int k = e / d, l = e - k * d, kg = c0 + k;
+                Xc[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
+            }
+            const double cal = nal, cw = nw;
+            {
+                const int c1n = c0 + ch;
+                nx = (xown && c1n + xk < n) ? Xtrain[(size_t)(c1n + xk) * d + xl] : 0.0;
+                nal = (eown && c1n + ek < n) ? alpha[c1n + ek] : 0.0;
+                nw = (eown && c1n + ek < n) ? wrow[c1n + ek] : 0.0;
+            }
+            __syncthreads();
+            for (int e = tid; e < a_cnt * ch; e += T) {
+                const int aa = e / ch, k = e - aa * ch, kg = c0 + k, a = a_lo + aa;
+                double v1 = 0.0, v2 = 0.0;
+                if (kg < n) {
+                    double t = 0.0;
+                    for (int l = 0; l < d; ++l) {
+                        const double df = xq[a * d + l] - Xc[k * dl + l];
+                        t += df * df * kp.inv_ls2[l];
+                    }
+                    double k0, k1, k2;
+                    kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+                    const double coef = (e == tid) ? pv[a] * cal - 2.0 * cw
+                                                   : pv[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg];
+                    v1 = coef * 2.0 * kp.variance * k1;
+                    v2 = coef * 4.0 * kp.variance * k2;
+                }
+                c1[aa * (ch + 1) + k] = v1;
+                c2[aa * (ch + 1) + k] = v2;
+            }
+            __syncthreads();
+            if (wave * na < a_cnt) {
+                for (int s4 = 0; s4 < ch; s4 += 4) {
+                    const int k = s4 + kk;
+                    const double diff = xa - Xc[k * dl + (r < d ? r : 0)];
+                    const double cc = (r < d ? c2 : c1)[ac * (ch + 1) + k];
+                    const double av = live ? (r < d ? cc * diff : cc) : 0.0;
+                    const double bv = live ? (r < d ? diff : 1.0) : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+            }
+        }
+        // tile -> the wave's scratch (row-major 16 x 16), then the diagonal blocks -> Dg
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wscratch[(kk + 4 * g) * 16 + li] = acc[g];
+        sens_sync<true>();
+        for (int e = lane; e < na * d * d; e += 64) {
+            const int ja = e / (d * d), rem = e - ja * d * d, l = rem / d, m2 = rem - l * d;
+            const int a = a_lo + wave * na + ja;
+            if (wave * na + ja < a_cnt) {
+                const int lo = min(l, m2), hi = max(l, m2);          // one triangle: exactly symmetric
+                double v = wscratch[(ja * dp + lo) * 16 + ja * dp + hi] * kp.inv_ls2[l] * kp.inv_ls2[m2];
+                if (l == m2) v += wscratch[(ja * dp + d) * 16 + ja * dp + d] * kp.inv_ls2[l];
+                Dg[(a * d + l) * d + m2] = v;
+            }
+        }
+        sens_sync<true>();
+    }
+    __syncthreads();
+}
+
 // self-covariance part of Dg: 2 sum_{c != a} M11_ac Hs_ac
 template <int T, typename MP, typename TP, typename DP>
 __device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, const lds_f64* xq,
@@ -648,7 +762,9 @@ __host__ __device__ inline size_t hess_dirs_shared_doubles(int q, int d) {
            (size_t)q * d + 3 * (size_t)q * q + (size_t)q * d * d;
 }
 __host__ __device__ inline size_t hess_dirs_wave_doubles(int q) {
-    return (size_t)2 * q * sdp_ld(q) + (size_t)HESS_WAVE_NVEC * sdp_vlen(q);
+    // at least the 16 x 16 tile of the Dg pre-pass
+    const size_t need = (size_t)2 * q * sdp_ld(q) + (size_t)HESS_WAVE_NVEC * sdp_vlen(q);
+    return need > 256 ? need : 256;
 }
 
 template <int T, int QE>
@@ -706,7 +822,10 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         for (int e = tid; e < 5 * VL; e += T) rc[e] = sb[3 * ML + e];     // rc sq rp c t1 likewise
     }
     __syncthreads();
-    hess_dg_prepass<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    if (d < 16)       // a point's d + 1 rows fit the 16-row tile
+        hess_dg_prepass_mfma<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, wbase, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    else
+        hess_dg_prepass<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
     build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
     const lds_f64* DS = tab;
     hess_dg_selfcov<T>(kp, q, xq, (const lds_f64*)M11, k1s, k2s, Dg);
