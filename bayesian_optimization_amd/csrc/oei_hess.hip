@@ -835,6 +835,24 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         phiS[a * LD + c] = -0.5 * sdp_rcp(sa * sc * (sa + sc));
         phiD[a * LD + c] = 0.5 * sdp_rcp(sa + sc);
     }
+    // L -> L^-1 in place (through the first wave's scratch): the directions solve with two
+    // matrix-vector products.  Lane j forms column j: X_jj = 1 / L_jj, X_ij = -(sum_{j<=k<i} L_ik X_kj) / L_ii.
+    if (wave == 0) {
+        lds_f64* Xi = wbase;
+        for (int e = lane; e < ML; e += 64) Xi[e] = 0.0;
+        sens_sync<true>();
+        if (lane < q) {
+            const int j = lane;
+            Xi[j * LD + j] = rc[j];
+            for (int i = j + 1; i < q; ++i) {
+                double acc = 0.0;
+                for (int k = j; k < i; ++k) acc = fma(L[i * LD + k], Xi[k * LD + j], acc);
+                Xi[i * LD + j] = -acc * rc[i];
+            }
+        }
+        sens_sync<true>();
+        for (int e = lane; e < ML; e += 64) L[e] = Xi[e];
+    }
     // Row (b,m) of the table becomes U^T v'_(b,m) (v'_j = dSigma_bj/dx_bm, j != b; half of it at
     // j = b), in place: it is both the direction's own input and what the contraction of every
     // other direction meets, so no direction forms dN = Y U^T.  A wave takes every NW-th row; lane t
@@ -878,7 +896,7 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
             ttpre[u] = gsym(Gb, RP, a * (d + 1) + 1 + l, bb * (d + 1) + 1 + m2);
         }
         if (lane < q) sv.dmu[lane] = (lane == a) ? dmuT[al] : 0.0;
-        sens_direction<64, true, true, QE, true>(w, sv, SensDir{a, nullptr, tab + (size_t)al * q, phiS, phiD, utc});
+        sens_direction<64, true, true, QE, true, true>(w, sv, SensDir{a, nullptr, tab + (size_t)al * q, phiS, phiD, utc});
         if (lane < q) dNmu[lane] = lds_dot(w.V + lane * LD, 1, utmu, 1, q);      // dN mu = Y (U^T mu)
         sens_sync<true>();
         hess_contract<true>(lane, 64, kp, q, RP, a, l, w.V, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, (const lds_f64*)M11, xq,

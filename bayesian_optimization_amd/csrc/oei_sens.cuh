@@ -228,7 +228,10 @@ struct SensDir {
 // already holds (the Hessian contraction: x = v' of every direction, c, mu), so the direction
 // stops at Y = U Z (in w.V; dN x = Y (U^T x)) and leaves out the product dN = Y U^T; its own
 // U^T v' comes in through sd.wv.  Out: Y in w.V, sv.w1 = N dc, sv.w2 = dN c = Y (U^T c), sv.dp.
-template <int T, bool WAVE, bool RANK2, int QE = 0, bool YFORM = false>
+// LINV (one wave): w.H holds L^-1 as a full matrix (zeros above the diagonal) instead of L, and
+// the two triangular solves become two matrix-vector products -- 2 q multiply-adds per lane with
+// no chain through the scalar unit, against 2 q dependent broadcast steps.
+template <int T, bool WAVE, bool RANK2, int QE = 0, bool YFORM = false, bool LINV = false>
 __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec sv, const SensDir sd) {
     constexpr int TT = WAVE ? 64 : T;
     const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
@@ -272,7 +275,16 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     double rhs = 0.0;
     if (tid < q) rhs = sv.dmu[tid] + lds_dot_rs(w.R + tid * LD, w.sq, Tb + tid, LD, sv.t2, q);
     // A x = rhs with A = L L^T = -hess g
-    if constexpr (TT == 64) {
+    if constexpr (LINV) {
+        static_assert(!LINV || TT == 64, "LINV is a one-wave form");
+        if (tid < q) sv.dp[tid] = rhs;
+        sens_sync<WAVE>();
+        const double y = (tid < q) ? lds_dot(w.H + tid * LD, 1, sv.dp, 1, q) : 0.0;      // L^-1 rhs
+        sens_sync<WAVE>();
+        if (tid < q) sv.rd[tid] = y;
+        sens_sync<WAVE>();
+        if (tid < q) sv.dp[tid] = -lds_dot(w.H + tid, LD, sv.rd, 1, q);                  // -L^-T y
+    } else if constexpr (TT == 64) {
         // one wave: the running vector stays in a register, solved components are broadcast
         // through the scalar unit; L is read from LDS (reads do not depend on the chain)
         const int row = tid < q ? tid : 0;
