@@ -503,8 +503,14 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
         double acc = 0.0;
         const auto dsrow = DS + (size_t)bm * q;
         if constexpr (WVFORM) {
+            // rows of the table are q doubles apart, so rows 8 apart start on the same LDS bank
+            // (q = 20): each of them walks its row from a different element
+            const int rot = q > 4 ? (bm >> 3) & 3 : 0;
 #pragma unroll 4
-            for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c];
+            for (int c = 0; c < q; ++c) {
+                const int cr = c + rot < q ? c + rot : c + rot - q;
+                acc += dN[bb * LD + cr] * dsrow[cr];
+            }
             acc *= 2.0;
         } else {
 #pragma unroll 4
@@ -855,18 +861,37 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     }
     // Row (b,m) of the table becomes U^T v'_(b,m) (v'_j = dSigma_bj/dx_bm, j != b; half of it at
     // j = b), in place: it is both the direction's own input and what the contraction of every
-    // other direction meets, so no direction forms dN = Y U^T.  A wave takes every NW-th row; lane t
-    // reads the whole row and column t of U, and the row is overwritten once all lanes have read it.
-    for (int bm = wave; bm < qd; bm += NW) {
-        const int bb = bm / d;
-        lds_f64* row = tab + (size_t)bm * q;
-        double acc = 0.0;
-        if (lane < q) {
-#pragma unroll 4
-            for (int c = 0; c < q; ++c) acc = fma(U[c * LD + lane], row[c] * (c == bb ? 0.5 : 1.0), acc);
+    // other direction meets, so no direction forms dN = Y U^T.  On the matrix pipe: a wave takes 16
+    // rows at a time (left operand: the rows, halved at c = b; right operand: U), reads them whole
+    // and only then overwrites them.
+    {
+        const int li = lane & 15, kg = lane >> 4, ks = (q + 3) >> 2;
+        for (int I = wave; 16 * I < qd; I += NW) {
+            sens_double4 acc0 = (sens_double4){0.0, 0.0, 0.0, 0.0}, acc1 = acc0;
+            const int bm = 16 * I + li;
+            const bool rin = bm < qd;
+            const int bmc = rin ? bm : 0, bb = bmc / d;
+            const bool j0 = li < q, j1 = 16 + li < q;
+            for (int s4 = 0; s4 < ks; ++s4) {
+                const int c = 4 * s4 + kg;
+                const bool kin = c < q;
+                const int cc = kin ? c : 0;
+                const double x = tab[(size_t)bmc * q + cc];
+                const double av = (rin && kin) ? (cc == bb ? 0.5 * x : x) : 0.0;
+                const double u0 = U[cc * LD + (j0 ? li : 0)], u1 = U[cc * LD + (j1 ? 16 + li : 0)];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (kin && j0) ? u0 : 0.0, acc0, 0, 0, 0);
+                if (q > 16) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, (kin && j1) ? u1 : 0.0, acc1, 0, 0, 0);
+            }
+            sens_sync<true>();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 16 * I + kg + 4 * g;
+                if (row < qd) {
+                    if (j0) tab[(size_t)row * q + li] = acc0[g];
+                    if (j1) tab[(size_t)row * q + 16 + li] = acc1[g];
+                }
+            }
         }
-        sens_sync<true>();
-        if (lane < q) row[lane] = acc;
     }
     if (tid < q) {
         utc[tid] = lds_dot(U + tid, LD, cv, 1, q);
