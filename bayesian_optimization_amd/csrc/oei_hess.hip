@@ -656,6 +656,21 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     }
     {
         const int lane = tid & 63, wave = tid >> 6;
+        // L^-1 for the directions' solves, column j by lane j of the first wave, into w.X (free
+        // until the first direction); copied over L behind the barrier
+        if (wave == 0) {
+            for (int e = lane; e < q * LD; e += 64) w.X[e] = 0.0;
+            sdp_wave_sync();
+            if (lane < q) {
+                const int j = lane;
+                w.X[j * LD + j] = w.rc[j];
+                for (int i = j + 1; i < q; ++i) {
+                    double acc = 0.0;
+                    for (int k = j; k < i; ++k) acc = fma(w.H[i * LD + k], w.X[k * LD + j], acc);
+                    w.X[i * LD + j] = -acc * w.rc[i];
+                }
+            }
+        }
         for (int bm = wave; bm < qd; bm += T / 64) {
             const int bb = bm / d;
             double* row = DS + (size_t)bm * q;
@@ -669,6 +684,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         }
     }
     __syncthreads();
+    for (int e = tid; e < q * LD; e += T) w.H[e] = w.X[e];
 
     // ---- one sensitivity solve per direction, fused with the contraction ------------------------
     for (int al = slice; al < qd; al += nslice) {

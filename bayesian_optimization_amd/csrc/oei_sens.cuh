@@ -368,7 +368,7 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
 // In: sv.dmu and the perturbation in rank-2 form dS = e_a v'^T + v' e_a^T through wv = U^T v'
 // (in LDS; overwritten).  Like the YFORM of sens_direction it stops at Y = U Z: out Y in w.V,
 // sv.w1 = N dc, sv.w2 = dN c = Y utc (utc = U^T c), sv.dp.
-// Needs w.rc = 1 / diag(L), w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1; scl is [q] scratch.
+// Needs L^-1 in w.H (full, zeros above the diagonal), w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1; scl is [q] scratch.
 template <int T>
 __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensVec sv, int a_dir,
                                                     lds_f64* wv, lds_f64* scl, const lds_f64* utc) {
@@ -401,31 +401,17 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         w.step[tid] = sv.dmu[tid] + acc;
     }
     __syncthreads();
-    // (-hess g) x = rhs with the factor L in w.H: the first wave alone, one row per lane, the
-    // running vector in a register and every solved component broadcast through the scalar unit
-    // (a workgroup-wide substitution costs two barriers per component: half of a direction's time)
-    if (tid < 64) {
-        const int row = tid < q ? tid : 0;
-        const double dinv = w.rc[row];
-        double bv = (tid < q) ? w.step[row] : 0.0;
-#pragma unroll 4
-        for (int k = 0; k < q; ++k) {                          // L y = rhs
-            const double lk = w.H[row * LD + k];
-            const double yk = sdp_lane_bcast(bv * dinv, k);
-            bv = (tid == k) ? yk : (tid > k ? bv - lk * yk : bv);
-        }
-#pragma unroll 4
-        for (int k = q - 1; k >= 0; --k) {                     // L^T x = y
-            const double lk = w.H[k * LD + row];
-            const double xk = sdp_lane_bcast(bv * dinv, k);
-            bv = (tid == k) ? xk : (tid < k ? bv - lk * xk : bv);
-        }
-        if (tid < q) {
-            const double dp = -bv, ipi = w.ip[tid];
-            sv.dp[tid] = dp;
-            scl[tid] = dp * ipi * ipi;
-            wv[tid] = dp * ipi;                                // wv is free again
-        }
+    // (-hess g) x = rhs through L^-1, which the caller keeps in w.H as a full matrix (zeros above
+    // the diagonal): two matrix-vector products, a row per thread.  (A substitution with L costs
+    // 2 q dependent steps in one wave, each a broadcast through the scalar unit, or two barriers
+    // per component across the workgroup.)
+    if (tid < q) sv.rd[tid] = lds_dot(w.H + tid * LD, 1, w.step, 1, q);        // y = L^-1 rhs
+    __syncthreads();
+    if (tid < q) {
+        const double dp = -lds_dot(w.H + tid, LD, sv.rd, 1, q), ipi = w.ip[tid];   // -L^-T y
+        sv.dp[tid] = dp;
+        scl[tid] = dp * ipi * ipi;
+        wv[tid] = dp * ipi;                                // wv is free again
     }
     __syncthreads();
     double sdp = 0.0;
