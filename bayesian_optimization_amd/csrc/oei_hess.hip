@@ -10,6 +10,7 @@
 //   GEMM         W = Z L^-1
 //   k_hess       state at p, one sensitivity solve per x-direction fused with the contraction
 //                <dM_(a,l), dOmega_(b,m)>, plus d2<Omega,M>/dx2 at fixed M in closed form
+#include <type_traits>
 #include "oei_sens.cuh"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -496,26 +497,10 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
                                               TP Dg, double* __restrict__ Hb,
                                               const double* ttpre = nullptr) {
     const int d = kp.d, dp = d + 1, qd = q * d, al = a * d + l;
-    int pass = 0;
-    for (int bm = tid; bm < qd; bm += nth, ++pass) {
+    // the part of entry (al, bm) that does not depend on <dN, dS_(b,m)> (`acc`), and the store
+    auto finish = [&](int bm, int pass, double acc) {
         const int bb = bm / d, m2 = bm - bb * d;
         // <dM, dOmega_(b,m)>, dM11 = -dN, dM[:q,q] = w1 + w2
-        double acc = 0.0;
-        const auto dsrow = DS + (size_t)bm * q;
-        if constexpr (WVFORM) {
-            // rows of the table are q doubles apart, so rows 8 apart start on the same LDS bank
-            // (q = 20): each of them walks its row from a different element
-            const int rot = q > 4 ? (bm >> 3) & 3 : 0;
-#pragma unroll 4
-            for (int c = 0; c < q; ++c) {
-                const int cr = c + rot < q ? c + rot : c + rot - q;
-                acc += dN[bb * LD + cr] * dsrow[cr];
-            }
-            acc *= 2.0;
-        } else {
-#pragma unroll 4
-            for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
-        }
         double P = -acc + 2.0 * dmuT[bm] * (w1[bb] + w2[bb] - dNmu[bb]);
         // d2<Omega,M>/dx2 at fixed M
         // T_al . T_bm: the first two passes may have been fetched ahead by the caller
@@ -531,6 +516,46 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
             inner += Dg[(a * d + l) * d + m2];
         }
         Hb[(size_t)al * qd + bm] = inner + P;
+    };
+    if constexpr (WVFORM && std::is_same<TP, const lds_f64*>::value) {
+        // two rows per thread and walk (bm and bm + nth): their dot products are independent
+        // chains, so one's LDS latency passes behind the other's.  Rows of the table are q doubles
+        // apart, so rows 8 apart start on the same LDS bank (q = 20): each row is walked from a
+        // different element.
+        int pass = 0;
+        for (int bm = tid; bm < qd; bm += 2 * nth, pass += 2) {
+            const bool two = bm + nth < qd;
+            const int bm2 = two ? bm + nth : bm;
+            const int bb = bm / d, bb2 = bm2 / d;
+            const auto row1 = DS + (size_t)bm * q, row2 = DS + (size_t)bm2 * q;
+            const int rot1 = q > 4 ? (bm >> 3) & 3 : 0, rot2 = q > 4 ? (bm2 >> 3) & 3 : 0;
+            double acc1 = 0.0, acc2 = 0.0;
+#pragma unroll 4
+            for (int c = 0; c < q; ++c) {
+                const int c1 = c + rot1 < q ? c + rot1 : c + rot1 - q;
+                const int c2 = c + rot2 < q ? c + rot2 : c + rot2 - q;
+                acc1 += dN[bb * LD + c1] * row1[c1];
+                acc2 += dN[bb2 * LD + c2] * row2[c2];
+            }
+            finish(bm, pass, 2.0 * acc1);
+            if (two) finish(bm2, pass + 1, 2.0 * acc2);
+        }
+    } else {
+        int pass = 0;
+        for (int bm = tid; bm < qd; bm += nth, ++pass) {
+            const int bb = bm / d;
+            double acc = 0.0;
+            const auto dsrow = DS + (size_t)bm * q;
+            if constexpr (WVFORM) {          // table in global memory (q > 32)
+#pragma unroll 4
+                for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c];
+                acc *= 2.0;
+            } else {
+#pragma unroll 4
+                for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
+            }
+            finish(bm, pass, acc);
+        }
     }
 }
 
