@@ -720,7 +720,11 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
             wv[tid] = DS[(size_t)al * q + tid];
         }
         sens_direction_lean<T>(w, sv, a, wv, scl, utc);
-        if (tid < q) dNmu[tid] = lds_dot(w.V + tid * LD, 1, utmu, 1, q);      // dN mu = Y (U^T mu)
+        {
+            const int ri = tid >> 2, row = ri < q ? ri : 0;
+            const double v = quad_row_sum(q, [&](int k) { return w.V[row * LD + k] * utmu[k]; });
+            if (ri < q && (tid & 3) == 0) dNmu[ri] = v;                        // dN mu = Y (U^T mu)
+        }
         __syncthreads();
         hess_contract<true>(tid, T, kp, q, RP, a, l, w.V, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
                             (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);

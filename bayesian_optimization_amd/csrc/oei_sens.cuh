@@ -358,6 +358,20 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     return dnu;
 }
 
+// A q-term sum per row for a 256-thread workgroup with q <= 64: threads 4 i .. 4 i + 3 share row i
+// (terms k = part, part + 4, ...) and add their parts with two quad exchanges; every thread of the
+// workgroup calls it, rows past q compute on row 0 and are discarded by the caller.
+template <class F>
+__device__ __forceinline__ double quad_row_sum(int q, F term) {
+    const int part = threadIdx.x & 3;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int k = part; k < q; k += 4) acc += term(k);
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    return acc;
+}
+
 // The same direction for a whole workgroup when LDS is short (q > 32 in the Hessian kernel): R is
 // not stored but expressed through U, R = diag(1/p) U + 1 rp^T, so that four q x q matrices
 // suffice: U (w.S), the factor L of -hess g (w.H) and two scratch matrices (w.X, w.V).  With
@@ -377,6 +391,10 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     const lds_f64* U = w.S;
     lds_f64* Tc = w.X;
     lds_f64* Tb = w.V;
+    // the q-term sums: four threads per row (T = 256 >= 4 q)
+    static_assert(T == 256, "four threads per row need 4 q <= T for every q <= 64");
+    const int ri = tid >> 2, row = ri < q ? ri : 0;
+    const bool rown = ri < q && (tid & 3) == 0;              // the thread that stores row ri's result
     __syncthreads();
     {
         const lds_f64* ua = U + a_dir * LD;
@@ -388,35 +406,46 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     }
     __syncthreads();
     lds_mm<T, false, true, true>(q, LD, Tc, U, Tb, w.sq);      // Tb = M1' = ZS diag(sq) U^T
-    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);
+    {
+        const double v = quad_row_sum(q, [&](int k) { return Tc[row * LD + k] * sv.t1[k]; });
+        if (rown) sv.t2[ri] = v;
+    }
     __syncthreads();
-    if (tid < q) {
+    {
         // rhs_i = dmu_i + sum_a R[i][a] sq[a] (M1[a][i] - 2 t2[a]),  M1[a][i] = M1'[a][i] / p_i + t2[a]
-        const double ipi = w.ip[tid];
-        double acc = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double r = fma(U[tid * LD + a], ipi, w.rp[a]);
-            acc = fma(r * w.sq[a], fma(ipi, Tb[a * LD + tid], -sv.t2[a]), acc);
-        }
-        w.step[tid] = sv.dmu[tid] + acc;
+        const double ipi = w.ip[row];
+        const double acc = quad_row_sum(q, [&](int a) {
+            const double r = fma(U[row * LD + a], ipi, w.rp[a]);
+            return r * w.sq[a] * fma(ipi, Tb[a * LD + row], -sv.t2[a]);
+        });
+        if (rown) w.step[ri] = sv.dmu[ri] + acc;
     }
     __syncthreads();
     // (-hess g) x = rhs through L^-1, which the caller keeps in w.H as a full matrix (zeros above
     // the diagonal): two matrix-vector products, a row per thread.  (A substitution with L costs
     // 2 q dependent steps in one wave, each a broadcast through the scalar unit, or two barriers
     // per component across the workgroup.)
-    if (tid < q) sv.rd[tid] = lds_dot(w.H + tid * LD, 1, w.step, 1, q);        // y = L^-1 rhs
+    {
+        const double y = quad_row_sum(q, [&](int k) { return w.H[row * LD + k] * w.step[k]; });    // y = L^-1 rhs
+        if (rown) sv.rd[ri] = y;
+    }
     __syncthreads();
-    if (tid < q) {
-        const double dp = -lds_dot(w.H + tid, LD, sv.rd, 1, q), ipi = w.ip[tid];   // -L^-T y
-        sv.dp[tid] = dp;
-        scl[tid] = dp * ipi * ipi;
-        wv[tid] = dp * ipi;                                // wv is free again
+    {
+        const double x = quad_row_sum(q, [&](int k) { return w.H[k * LD + row] * sv.rd[k]; });     // L^-T y
+        if (rown) {
+            const double dp = -x, ipi = w.ip[ri];
+            sv.dp[ri] = dp;
+            scl[ri] = dp * ipi * ipi;
+            wv[ri] = dp * ipi;                             // wv is free again
+        }
     }
     __syncthreads();
     double sdp = 0.0;
     for (int i = 0; i < q; ++i) sdp += sv.dp[i];
-    if (tid < q) sv.rd[tid] = lds_dot(U + tid, LD, wv, 1, q) + w.rp[tid] * sdp;
+    {
+        const double h = quad_row_sum(q, [&](int k) { return U[k * LD + row] * wv[k]; });
+        if (rown) sv.rd[ri] = h + w.rp[ri] * sdp;
+    }
     lds_mm<T, true, false, true>(q, LD, U, U, Tb, scl);        // Tb = U^T diag(dp / p^2) U
     __syncthreads();
     for (int e = tid; e < q * q; e += T) {                     // Z = ZS + Phi o (R^T dD R) / 4
@@ -426,24 +455,33 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     }
     __syncthreads();
     lds_mm<T, false, false, false>(q, LD, U, Tc, Tb);          // Tb = Y = U Z
-    if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);        // Z t1
-    __syncthreads();
-    if (tid < q) {
-        // dc = dmu + sum_a R[i][a] sq[a] (rd[a] - 2 t2[a])
-        const double ipi = w.ip[tid];
-        double acc = 0.0;
-        for (int a = 0; a < q; ++a) {
-            const double r = fma(U[tid * LD + a], ipi, w.rp[a]);
-            acc = fma(r * w.sq[a], fma(-2.0, sv.t2[a], sv.rd[a]), acc);
-        }
-        sv.dc[tid] = sv.dmu[tid] + acc;
+    {
+        const double v = quad_row_sum(q, [&](int k) { return Tc[row * LD + k] * sv.t1[k]; });      // Z t1
+        if (rown) sv.t2[ri] = v;
     }
     __syncthreads();
-    if (tid < q) wv[tid] = lds_dot(U + tid, LD, sv.dc, 1, q) * sdp_rcp(w.sq[tid]);   // (U^T dc) / sq
+    {
+        // dc = dmu + sum_a R[i][a] sq[a] (rd[a] - 2 t2[a])
+        const double ipi = w.ip[row];
+        const double acc = quad_row_sum(q, [&](int a) {
+            const double r = fma(U[row * LD + a], ipi, w.rp[a]);
+            return r * w.sq[a] * fma(-2.0, sv.t2[a], sv.rd[a]);
+        });
+        if (rown) sv.dc[ri] = sv.dmu[ri] + acc;
+    }
     __syncthreads();
-    if (tid < q) {
-        sv.w1[tid] = 0.5 * lds_dot(U + tid * LD, 1, wv, 1, q);          // N dc
-        sv.w2[tid] = lds_dot(Tb + tid * LD, 1, utc, 1, q);              // dN c = Y (U^T c)
+    {
+        const double v = quad_row_sum(q, [&](int k) { return U[k * LD + row] * sv.dc[k]; });
+        if (rown) wv[ri] = v * sdp_rcp(w.sq[ri]);            // (U^T dc) / sq
+    }
+    __syncthreads();
+    {
+        const double v1 = quad_row_sum(q, [&](int k) { return U[row * LD + k] * wv[k]; });
+        const double v2 = quad_row_sum(q, [&](int k) { return Tb[row * LD + k] * utc[k]; });
+        if (rown) {
+            sv.w1[ri] = 0.5 * v1;                             // N dc
+            sv.w2[ri] = v2;                                   // dN c = Y (U^T c)
+        }
     }
     __syncthreads();
 }
