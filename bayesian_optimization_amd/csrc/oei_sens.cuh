@@ -144,9 +144,11 @@ __device__ __forceinline__ void sens_sync() {
 // stores per lane instead of about 100 reads and 125 multiply-adds, and the vector unit stays free
 // for the wave that shares the SIMD.  Entries past q are supplied as zeros.
 typedef double sens_double4 __attribute__((ext_vector_type(4)));
+// I0, J0: first row and column tile of the NT x NT tiles this wave computes (a workgroup of four
+// waves covers q <= 64 with NT = 2 and (I0, J0) = (0,0), (0,2), (2,0), (2,2)).
 template <int NT, bool TA, bool TB, bool SC>
 __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_f64* A, const lds_f64* B,
-                                             lds_f64* C, const lds_f64* sc) {
+                                             lds_f64* C, const lds_f64* sc, int I0 = 0, int J0 = 0) {
     const int li = lane & 15, kg = lane >> 4;
     sens_double4 acc[NT][NT];
 #pragma unroll
@@ -162,7 +164,7 @@ __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_
         const double scale = SC ? sc[kc] : 1.0;
 #pragma unroll
         for (int I = 0; I < NT; ++I) {
-            const int i = 16 * I + li;
+            const int i = 16 * (I0 + I) + li;
             const bool in = kin && i < q;
             const int ic = in ? i : 0;
             const double x = A[TA ? kc * LD + ic : ic * LD + kc];
@@ -170,7 +172,7 @@ __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_
         }
 #pragma unroll
         for (int J = 0; J < NT; ++J) {
-            const int j = 16 * J + li;
+            const int j = 16 * (J0 + J) + li;
             const bool in = kin && j < q;
             const int jc = in ? j : 0;
             const double x = B[TB ? jc * LD + kc : kc * LD + jc];
@@ -188,7 +190,7 @@ __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_
         for (int J = 0; J < NT; ++J)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int i = 16 * I + kg + 4 * g, j = 16 * J + li;
+                const int i = 16 * (I0 + I) + kg + 4 * g, j = 16 * (J0 + J) + li;
                 if (i < q && j < q) C[i * LD + j] = acc[I][J][g];
             }
 }
@@ -202,6 +204,15 @@ __device__ __forceinline__ void sens_mm(int tid, int q, int LD, const lds_f64* A
     } else {
         lds_mm<T, TA, TB, SC>(q, LD, A, B, C, sc);
     }
+}
+
+// The product for a 256-thread workgroup and q <= 64 on the matrix pipe: wave w computes the
+// 32 x 32 block (w >> 1, w & 1) of C; a block that lies past q altogether is skipped.
+template <bool TA, bool TB, bool SC>
+__device__ __forceinline__ void wg4_mm_mfma(int q, int LD, const lds_f64* A, const lds_f64* B, lds_f64* C,
+                                            const lds_f64* sc = nullptr) {
+    const int wave = threadIdx.x >> 6, I0 = 2 * (wave >> 1), J0 = 2 * (wave & 1);
+    if (16 * I0 < q && 16 * J0 < q) wave_mm_mfma<2, TA, TB, SC>(threadIdx.x & 63, q, LD, A, B, C, sc, I0, J0);
 }
 
 // What a direction reads besides the solver state: the perturbation itself and, optionally,
@@ -405,7 +416,7 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         }
     }
     __syncthreads();
-    lds_mm<T, false, true, true>(q, LD, Tc, U, Tb, w.sq);      // Tb = M1' = ZS diag(sq) U^T
+    wg4_mm_mfma<false, true, true>(q, LD, Tc, U, Tb, w.sq);    // Tb = M1' = ZS diag(sq) U^T
     {
         const double v = quad_row_sum(q, [&](int k) { return Tc[row * LD + k] * sv.t1[k]; });
         if (rown) sv.t2[ri] = v;
@@ -446,7 +457,7 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         const double h = quad_row_sum(q, [&](int k) { return U[k * LD + row] * wv[k]; });
         if (rown) sv.rd[ri] = h + w.rp[ri] * sdp;
     }
-    lds_mm<T, true, false, true>(q, LD, U, U, Tb, scl);        // Tb = U^T diag(dp / p^2) U
+    wg4_mm_mfma<true, false, true>(q, LD, U, U, Tb, scl);      // Tb = U^T diag(dp / p^2) U
     __syncthreads();
     for (int e = tid; e < q * q; e += T) {                     // Z = ZS + Phi o (R^T dD R) / 4
         const int a = e / q, b = e - a * q;
@@ -454,7 +465,7 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         Tc[a * LD + b] += acc * (0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
     __syncthreads();
-    lds_mm<T, false, false, false>(q, LD, U, Tc, Tb);          // Tb = Y = U Z
+    wg4_mm_mfma<false, false, false>(q, LD, U, Tc, Tb);        // Tb = Y = U Z
     {
         const double v = quad_row_sum(q, [&](int k) { return Tc[row * LD + k] * sv.t1[k]; });      // Z t1
         if (rown) sv.t2[ri] = v;
