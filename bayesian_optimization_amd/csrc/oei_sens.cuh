@@ -195,17 +195,6 @@ __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_
             }
 }
 
-template <int T, bool WAVE, bool TA, bool TB, bool SC>
-__device__ __forceinline__ void sens_mm(int tid, int q, int LD, const lds_f64* A, const lds_f64* B,
-                                        lds_f64* C, const lds_f64* sc = nullptr) {
-    if constexpr (WAVE) {
-        if (q <= 16) wave_mm_mfma<1, TA, TB, SC>(tid, q, LD, A, B, C, sc);
-        else wave_mm_mfma<2, TA, TB, SC>(tid, q, LD, A, B, C, sc);
-    } else {
-        lds_mm<T, TA, TB, SC>(q, LD, A, B, C, sc);
-    }
-}
-
 // The product for a 256-thread workgroup and q <= 64 on the matrix pipe: wave w computes the
 // 32 x 32 block (w >> 1, w & 1) of C; a block that lies past q altogether is skipped.
 template <bool TA, bool TB, bool SC>
@@ -213,6 +202,19 @@ __device__ __forceinline__ void wg4_mm_mfma(int q, int LD, const lds_f64* A, con
                                             const lds_f64* sc = nullptr) {
     const int wave = threadIdx.x >> 6, I0 = 2 * (wave >> 1), J0 = 2 * (wave & 1);
     if (16 * I0 < q && 16 * J0 < q) wave_mm_mfma<2, TA, TB, SC>(threadIdx.x & 63, q, LD, A, B, C, sc, I0, J0);
+}
+
+template <int T, bool WAVE, bool TA, bool TB, bool SC>
+__device__ __forceinline__ void sens_mm(int tid, int q, int LD, const lds_f64* A, const lds_f64* B,
+                                        lds_f64* C, const lds_f64* sc = nullptr) {
+    if constexpr (WAVE) {
+        if (q <= 16) wave_mm_mfma<1, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+        else wave_mm_mfma<2, TA, TB, SC>(tid, q, LD, A, B, C, sc);
+    } else if constexpr (T == 256) {
+        wg4_mm_mfma<TA, TB, SC>(q, LD, A, B, C, sc);
+    } else {
+        lds_mm<T, TA, TB, SC>(q, LD, A, B, C, sc);
+    }
 }
 
 // What a direction reads besides the solver state: the perturbation itself and, optionally,
