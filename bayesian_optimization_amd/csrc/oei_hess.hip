@@ -546,10 +546,21 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
             const int bb = bm / d;
             double acc = 0.0;
             const auto dsrow = DS + (size_t)bm * q;
-            if constexpr (WVFORM) {          // table in global memory (q > 32)
-#pragma unroll 4
-                for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c];
-                acc *= 2.0;
+            if constexpr (WVFORM) {          // table in global memory (q > 32): ten loads in flight
+                double acc1 = 0.0;
+                int c = 0;
+                for (; c + 10 <= q; c += 10) {
+                    double tv[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) tv[u] = dsrow[c + u];
+#pragma unroll
+                    for (int u = 0; u < 10; u += 2) {
+                        acc = fma(dN[bb * LD + c + u], tv[u], acc);
+                        acc1 = fma(dN[bb * LD + c + u + 1], tv[u + 1], acc1);
+                    }
+                }
+                for (; c < q; ++c) acc = fma(dN[bb * LD + c], dsrow[c], acc);
+                acc = 2.0 * (acc + acc1);
             } else {
 #pragma unroll 4
                 for (int c = 0; c < q; ++c) acc += dN[bb * LD + c] * dsrow[c] * (c == bb ? 1.0 : 2.0);
