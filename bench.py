@@ -303,8 +303,8 @@ def main():
             # the timed region: a few calls on a slice of this rank's candidates
             if not args.no_hessian:
                 hb = min(B, 2048)
-                hreps = 10
-                for _ in range(3):                      # buffers, then clocks
+                hreps = 20
+                for _ in range(5):                      # buffers, then clocks
                     gp.hessian(X_local[:hb])
                 torch.cuda.synchronize()
                 th = time.perf_counter()
