@@ -34,6 +34,7 @@ SIGNATURES = {
     'oei_value_grad_warm_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oei_value_grad_batched_noalloc': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, vp]),
     'oei_hessian_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
+    'oei_project_flags': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     'oei_domega_batched': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     'oei_set_profiling': (ctypes.c_int, [vp, ctypes.c_int]),
     'oei_get_stage_times': (ctypes.c_int, [vp, vp]),

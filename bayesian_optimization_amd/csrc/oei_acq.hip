@@ -293,8 +293,8 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
                                               double* __restrict__ p_out,
                                               double* __restrict__ M11_out,
                                               double* __restrict__ Z,
-                                              const double* __restrict__ start_in,
-                                              double* __restrict__ start_out,
+                                              const double* start_in,
+                                              double* start_out,
                                               int* __restrict__ iters_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     OEI_LDS_POISON(sm);
@@ -809,12 +809,15 @@ static int value_grad_pipelined(oei_model* m, int B, int q, const double* X, dou
         if (!m->ev_join[i]) OEI_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
     }
     if (!m->ev_fork) OEI_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    OEI_HIP_CHECK(hipEventRecord(m->ev_fork, st));
-    for (int i = 0; i < nstreams; ++i) OEI_HIP_CHECK(hipStreamWaitEvent(m->side[i], m->ev_fork, 0));
+    OEI_HIP_CHECK(hipEventRecord(m->ev_fork, st));      // nothing is on the side streams yet: plain returns up to here
+    rc = OEI_OK;
+    for (int i = 0; i < nstreams && rc == OEI_OK; ++i) {
+        const hipError_t e = hipStreamWaitEvent(m->side[i], m->ev_fork, 0);
+        if (e != hipSuccess) { oei_set_error("value_grad: fork to side stream %d failed: %s", i, hipGetErrorString(e)); rc = OEI_ERR_HIP; }
+    }
     const int d = m->d;
     int c = 0;
-    rc = OEI_OK;
-    for (int b0 = 0; b0 < B; b0 += per, ++c) {
+    for (int b0 = 0; b0 < B && rc == OEI_OK; b0 += per, ++c) {
         const int bc = (B - b0 < per) ? B - b0 : per;
         const size_t row0 = (size_t)b0 * q * m->npad;
         rc = value_grad_run(m, bc, q, X + (size_t)b0 * q * d, value + b0, grad + (size_t)b0 * q * d, status + b0,
@@ -824,9 +827,20 @@ static int value_grad_pipelined(oei_model* m, int B, int q, const double* X, dou
                             start_out ? start_out + (size_t)b0 * q : nullptr, iters ? iters + b0 : nullptr);
         if (rc) break;                                   // the caller's stream still joins what was enqueued
     }
+    // Always join: whatever was enqueued on the side streams must be ordered before the caller's
+    // stream goes on, also after an error (the caller may release X, the outputs or the handle).
+    // If the event route fails the side stream is drained on the host instead.  After an error
+    // return the contents of the outputs are undefined.
     for (int i = 0; i < nstreams; ++i) {
-        OEI_HIP_CHECK(hipEventRecord(m->ev_join[i], m->side[i]));
-        OEI_HIP_CHECK(hipStreamWaitEvent(st, m->ev_join[i], 0));
+        hipError_t e = hipEventRecord(m->ev_join[i], m->side[i]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, m->ev_join[i], 0);
+        if (e != hipSuccess) {
+            hipStreamSynchronize(m->side[i]);
+            if (rc == OEI_OK) {
+                oei_set_error("value_grad: joining side stream %d failed: %s", i, hipGetErrorString(e));
+                rc = OEI_ERR_HIP;
+            }
+        }
     }
     return rc;
 }
@@ -916,10 +930,63 @@ extern "C" int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const 
         return OEI_ERR_ARG;
     }
     if (m->device < 0 || m->device >= OEI_MAX_DEVICES) { oei_set_error("noalloc: device %d out of range", m->device); return OEI_ERR_ARG; }
+    int cur = -1;
+    OEI_HIP_CHECK(hipGetDevice(&cur));
+    if (cur != m->device) {      // the launches below go to the current device; the scratch address belongs to the model's
+        oei_set_error("value_grad_batched_noalloc: the model lives on device %d, the current device is %d", m->device, cur);
+        return OEI_ERR_ARG;
+    }
     if (!scratch_ptr[m->device] && (rc = oei_noalloc_setup_device(m->device))) return rc;
     double* base = scratch_ptr[m->device];
     return value_grad_run(m, B, q, X, value, grad, status, flags, (hipStream_t)stream,
                           base, base + buf, base + 2 * buf, base + 3 * buf);
+}
+
+// ---- the duplicate tests of `project` alone (oei.py:181-192) ---------------------------------------
+// flags[b] = 1 when a point of candidate b lies within 1e-2 lengthscales of a training input in
+// every coordinate, or two of its points are equal after rounding X/l to two decimals: the same
+// two tests, in the same arithmetic, that the Gram kernel and the finishing kernel of the
+// value+gradient path apply.
+__global__ __launch_bounds__(256) void k_project_flags(KernParams kp, int n, int q,
+                                                       const double* __restrict__ Xtrain,
+                                                       const double* __restrict__ Xq,
+                                                       int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    OEI_LDS_POISON(sm);
+    const int d = kp.d, tid = threadIdx.x, b = blockIdx.x;
+    double* xq = sm;                              // [q][d]
+    for (int e = tid; e < q * d; e += 256) xq[e] = Xq[(size_t)b * q * d + e];
+    __syncthreads();
+    int flag = 0;
+    for (int e = tid; e < q * n; e += 256) {
+        const int a = e / n, k = e - a * n;
+        bool close = true;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[a * d + l] - Xtrain[(size_t)k * d + l];
+            close = close && (fabs(df * kp.inv_ls[l]) < 1e-2);
+        }
+        if (close) flag = 1;
+    }
+    for (int e = tid; e < q * q; e += 256) {
+        const int a = e / q, bb = e - a * q;
+        bool same = true;
+        for (int l = 0; l < d; ++l)
+            same = same && (rint(xq[a * d + l] / kp.ls[l] * 100.0) == rint(xq[bb * d + l] / kp.ls[l] * 100.0));
+        if (a != bb && same) flag = 1;
+    }
+    flag = __syncthreads_or(flag);
+    if (tid == 0) flags[b] = flag ? 1 : 0;
+}
+
+extern "C" int oei_project_flags(oei_model* m, int B, int q, const double* X, int* flags, void* stream) {
+    int rc = check_model_call(m, B, q, X, "project_flags");
+    if (rc) return rc;
+    if (B == 0) return OEI_OK;
+    if (!flags) { oei_set_error("project_flags: null output"); return OEI_ERR_ARG; }
+    hipLaunchKernelGGL(k_project_flags, dim3(B), dim3(256), (size_t)q * m->d * sizeof(double), (hipStream_t)stream,
+                       m->kp, m->n, q, m->X, X, flags);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
 }
 
 extern "C" int oei_set_profiling(oei_model* m, int on) {

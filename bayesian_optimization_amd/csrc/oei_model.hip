@@ -196,6 +196,15 @@ extern "C" int oei_model_refactor(oei_model* m, int kernel_kind, int floor_mode,
     int cur = -1;
     OEI_HIP_CHECK(hipGetDevice(&cur));
     if (cur != m->device) OEI_HIP_CHECK(hipSetDevice(m->device));
+    // Evaluations of this handle may still be in flight on the caller's streams or on the handle's
+    // side streams (non-blocking streams are not ordered against the null stream the
+    // factorisation runs on); they read the factors that are rewritten below.
+    const hipError_t se = hipDeviceSynchronize();
+    if (se != hipSuccess) {
+        if (cur != m->device) hipSetDevice(cur);
+        oei_set_error("model_refactor: hipDeviceSynchronize failed: %s", hipGetErrorString(se));
+        return OEI_ERR_HIP;
+    }
     rc = factorise(m);
     if (cur != m->device) hipSetDevice(cur);
     return rc;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64) void k_newton_init(NewtonView V, const double* 
 // the free variables, the identity on the blocked ones, plus lam on the diagonal.
 __device__ __forceinline__ double masked_h(const double* __restrict__ H, int n, int i, int j,
                                            const double* fm, double lam) {
-    double a = H[(size_t)i * n + j], b = H[(size_t)j * n + i];
+    double a = H ? H[(size_t)i * n + j] : 0.0, b = H ? H[(size_t)j * n + i] : 0.0;   // no list: a zero matrix
     if (!isfinite(a)) a = 0.0;
     if (!isfinite(b)) b = 0.0;
     double v = 0.5 * (a + b) * fm[i] * fm[j];
@@ -128,8 +128,9 @@ __global__ __launch_bounds__(NT) void k_newton_step(NewtonView V, const double* 
     double t = V.t[r];
     int nit = V.nit[r];
     if (V.phase[r] == PH_TRIAL) {
-        const double fv = ft[c];
-        const double* gn = gt + (size_t)c * n;
+        // a run that waits for a trial value while the caller passed no list sees a rejected point
+        const double fv = (ft && gt) ? ft[c] : INFINITY;
+        const double* gn = (ft && gt) ? gt + (size_t)c * n : g;
         const int nfev = V.nfev[r] + 1;
         __syncthreads();
         if (tid == 0) V.nfev[r] = nfev;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(NT) void k_newton_step(NewtonView V, const double* 
         return;
     }
     // ---- Hessian at the iterate: direction and first trial point --------------------------------
-    const double* H = Ht + (size_t)c * n * n;
+    const double* H = Ht ? Ht + (size_t)c * n * n : nullptr;
     if (tid == 0) V.nhev[r] += 1;
     for (int i = tid; i < n; i += NT) {
         const bool blocked = (x[i] <= lo[i] && g[i] > 0.0) || (x[i] >= hi[i] && g[i] < 0.0);

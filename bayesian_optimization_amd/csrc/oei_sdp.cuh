@@ -1354,8 +1354,8 @@ __device__ __forceinline__ int sdp_newton_dir_s(const SdpWork w) {
 // 1e-4 of the box).  Used when the product lies inside the simplex.
 template <int T, int Q, bool EXACT>
 __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, int* iters_out,
-                                              const double* __restrict__ start_in = nullptr,
-                                              double* __restrict__ start_out = nullptr) {
+                                              const double* start_in = nullptr,
+                                              double* start_out = nullptr) {
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     // closed-form q = 1 weights, shrunk into the simplex
@@ -1457,8 +1457,8 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
 
 template <int T, int Q>
 __device__ __forceinline__ int sdp_solve(const SdpWork w, double* g_out, int* iters_out,
-                                         const double* __restrict__ start_in = nullptr,
-                                         double* __restrict__ start_out = nullptr) {
+                                         const double* start_in = nullptr,
+                                         double* start_out = nullptr) {
     if constexpr (Q > 0) {
         return (w.q == Q) ? sdp_solve_impl<T, Q, true>(w, g_out, iters_out, start_in, start_out)
                           : sdp_solve_impl<T, Q, false>(w, g_out, iters_out, start_in, start_out);

@@ -204,6 +204,16 @@ class DeviceGP:
                   'oei_hessian_batched')
         return H, status
 
+    def project_flags(self, X):
+        """[B,q,d] -> int32 [B]: 1 where the reference's `project` (oei.py:181-192) would remove a
+        point of the candidate (duplicate of a training input, or two equal points)."""
+        X = self._batch(X)
+        B, q, _ = X.shape
+        flags = torch.empty(B, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.oei_project_flags(self._h, B, q, _ptr(X), _ptr(flags), _stream()), 'oei_project_flags')
+        return flags
+
     def domega(self, X):
         X = self._batch(X)
         B, q, d = X.shape

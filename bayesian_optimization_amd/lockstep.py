@@ -348,8 +348,12 @@ def acquisition_hess_fun(gp, q):
 
     def hess(X):
         b = X.shape[0]
-        H, status = gp.hessian(X.reshape(b, q, d))
-        return torch.where((status == 0)[:, None, None], H, torch.zeros_like(H))
+        Xb = X.reshape(b, q, d)
+        H, status = gp.hessian(Xb)
+        keep = status == 0
+        if gp.noise <= 1e-4:                      # `project` is the identity above that (oei.py:174-175)
+            keep = keep & (gp.project_flags(Xb) == 0)
+        return torch.where(keep[:, None, None], H, torch.zeros_like(H))
     return hess
 
 

@@ -12,7 +12,10 @@ GPU to machine precision by a Newton iteration on its reduced dual (csrc/oei_sdp
 cross-call warm start that the reference needs for SCS (sdp.py:77-121) has nothing to speed up:
 `warm_start` is accepted and ignored, `reset_warm_starting()` clears an (unused) history so that
 callers such as bo.py:146 keep working.  As in the reference a failed solve never raises: a warning
-goes to the 'opt' logger (sdp.py:53-56); NaN in omega raises AssertionError (sdp.py:35).
+goes to the 'opt' logger (sdp.py:53-56); NaN in omega raises AssertionError (sdp.py:35).  A
+positive semidefinite but singular omega is solved on omega + eps I (status 'Iteration limit' in
+the warning: the result is that of a neighbouring problem); a matrix with a negative eigenvalue
+gives NaN.
 """
 import collections
 import logging
@@ -55,6 +58,21 @@ def sdp(omega, fmin, warm_start=True):
     fmin_s = float(np.asarray(fmin).reshape(-1)[0])
     value, M, Y, status, _ = engine.sdp_batched(omega[None], np.array([fmin_s]))
     st = int(status.item())
+    if st != 0:
+        # The device solver needs a positive definite covariance block; SCS in the reference takes
+        # any symmetric matrix (sdp.py:34-67).  A positive semidefinite but singular Omega has a
+        # finite optimum that depends continuously on Omega: solve Omega + eps I, eps from
+        # 1e-12 tr(Omega)/k_ upwards, and report the first that converges, with a warning.
+        tr = float(np.trace(omega)) / k_
+        for eps in (1e-12, 1e-10, 1e-8):
+            if not (tr > 0):
+                break
+            v2, M2, Y2, s2, _ = engine.sdp_batched((omega + eps * tr * np.eye(k_))[None], np.array([fmin_s]))
+            if int(s2.item()) == 0:
+                value, M, Y, st = v2, M2, Y2, 1
+                logging.getLogger('opt').warning('SDP: Omega is singular to working precision, solved on the '
+                                                 'regularised matrix Omega + %.0e tr(Omega)/k I' % eps)
+                break
     if st != 0:
         logging.getLogger('opt').warning('SDP solution status:' + engine.STATUS_TEXT.get(st, str(st)))
     M = M[0].cpu().numpy()

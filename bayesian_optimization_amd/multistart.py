@@ -30,10 +30,11 @@ def make_record(best_value, best_index, X_best):
     return rec
 
 
-def select_best(rec, group=None):
+def select_best(rec, group=None, force=False):
     """All-gather the per-rank records and return (value, index, X_flat) of the winner.
-    Without an initialised process group the local record wins."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    Without an initialised process group the local record wins.  `force`: run the collective also
+    in a group of one rank (exercises the RCCL path on a single GPU)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         world = dist.get_world_size(group)
         # RCCL gathers device tensors in place; gloo (CPU tests, one-GPU rehearsals) gets host copies
         src = rec.contiguous() if dist.get_backend(group) != 'gloo' else rec.detach().cpu().contiguous()
@@ -58,14 +59,14 @@ def select_best(rec, group=None):
     return row[0], indices.index_select(0, win).reshape(()), row[2:]
 
 
-def evaluate_and_select(gp, X_local, index_base=0, group=None):
+def evaluate_and_select(gp, X_local, index_base=0, group=None, force_collective=False):
     """Evaluate value+gradient of the local shard on the GPU, then pick the global best start.
     Returns (value [B], grad [B,q,d], status [B], (best_value, best_index, best_X [q,d]))."""
     from . import engine
     value, grad, status, _ = gp.value_grad(X_local, want_flags=False)
     rec = engine.best_record(value, X_local, index_base)      # one launch: arg-min + record
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        best_value, best_index, best_X = select_best(rec, group)
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective):
+        best_value, best_index, best_X = select_best(rec, group, force=force_collective)
     else:                                                     # one rank: its record is the winner
         best_value, best_index, best_X = rec[0], rec[1:2].view(torch.int64).reshape(()), rec[2:]
     return value, grad, status, (best_value, best_index, best_X.reshape(X_local.shape[1:]))

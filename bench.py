@@ -145,6 +145,9 @@ def main():
                          'by default batches of two solver rounds and more run as two halves on two internal streams')
     ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' only for rehearsing N > 1 on one GPU or on the CPU")
     ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses GPU 0')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='with --gpus 1: create a process group of one rank and send the best-start record through '
+                         'the all-gather anyway (loads RCCL and runs the collective on a single GPU)')
     ap.add_argument('--rehearse-cpu', action='store_true',
                     help='rehearsal of the launcher, the sharding and the best-start exchange without a GPU: '
                          'the evaluation is replaced by a closed-form stand-in; the printed rate means nothing')
@@ -168,7 +171,13 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)            # before the package import: its context goes here
         dev = torch.device('cuda', local_rank)
-    if world > 1:
+    grouped = world > 1 or args.force_collective
+    if grouped:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)
         else:
@@ -194,7 +203,7 @@ def main():
             value = torch.sin(3.0 * X_local).sum(dim=(1, 2)) + X_local[:, 0, 0] ** 2
             li = torch.argmin(value).reshape(1)
             rec = multistart.make_record(value[li], li + lo, X_local.reshape(hi - lo, -1)[li])
-            bv, bi, bx = multistart.select_best(rec)
+            bv, bi, bx = multistart.select_best(rec, force=args.force_collective)
             return value, None, torch.zeros(hi - lo, dtype=torch.int32), (bv, bi, bx.reshape(q, d))
 
         def sync():
@@ -208,21 +217,21 @@ def main():
             gp.set_pipelining(False)
 
         def step():
-            return multistart.evaluate_and_select(gp, X_local, index_base=lo)
+            return multistart.evaluate_and_select(gp, X_local, index_base=lo, force_collective=args.force_collective)
 
         sync = torch.cuda.synchronize
 
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
@@ -363,9 +372,10 @@ def main():
                                   '`roofline` are whole-batch launches on one stream)',
                        'parallelism': 'candidates sharded over %d rank(s) (%s), one GPU each, '
                                       'one all-gather of a %d-byte record'
-                                      % (world, ('world size seen by ' + args.backend) if world > 1 else 'no process group',
+                                      % (world, ('world size seen by ' + args.backend) if grouped else 'no process group',
                                          8 * (2 + q * d))},
             'unconverged': n_bad,
+            'collective': ('all_gather_into_tensor of the record over %s, %d rank(s)' % (args.backend, world)) if grouped else None,
             'best': {'value': float(best[0].item()), 'index': int(best[1].item()),
                      'x_sha1': hashlib.sha1(bx.tobytes()).hexdigest()},
             'hessian': hessian, 'callers': callers, 'roofline': roofline, 'cpu_baseline': cpu,
@@ -373,7 +383,7 @@ def main():
         if cpu_only:
             result['data'] = 'synthetic; CPU rehearsal of the launcher (stand-in evaluation, rate meaningless)'
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return result

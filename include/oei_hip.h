@@ -72,7 +72,10 @@ int oei_model_destroy(oei_model* m);
 /* Same data, new hyper-parameters: recomputes K, its factor, L^-1, L^-1 y and fmin in the handle's
  * existing buffers (no device allocation or release).  This is one objective evaluation of the
  * hyper-parameter fit (bo.py:194-221: gpflow's optimize() re-runs the Cholesky of the same X, y for
- * every trial parameter vector).  Synchronous.  After OEI_ERR_NOT_PD the handle stays valid for
+ * every trial parameter vector).  Synchronous, and ordered after everything already enqueued on
+ * the model's device: it first waits for the device (hipDeviceSynchronize), because evaluations
+ * of this handle that are still in flight on any stream read the factors it rewrites.  Evaluations
+ * enqueued after it returns see the new factors.  After OEI_ERR_NOT_PD the handle stays valid for
  * another oei_model_refactor, but not for evaluations. */
 int oei_model_refactor(oei_model* m, int kernel_kind, int floor_mode, double variance,
                        const double* lengthscales, int n_lengthscales, double noise);
@@ -120,7 +123,8 @@ int oei_value_grad_batched(oei_model* m, int B, int q, const double* X,
  * start_in device [B,q] or NULL holds, per candidate, the state a previous call wrote for a nearby X
  * (opaque: the ratio of the optimal to the closed-form start weights; a NaN, or a product outside
  * the simplex, means "no start" and the closed-form start is used); start_out device [B,q] or NULL
- * receives this solve's state (may equal start_in); iters device int[B] or NULL the Newton
+ * receives this solve's state (may equal start_in: a candidate's state is read before it is
+ * written and the kernels do not assume the two are distinct); iters device int[B] or NULL the Newton
  * iteration count (low 16 bits) and Jacobi sweeps (high bits).  The converged result does not
  * depend on the start beyond the solver's tolerance (about 1e-10 relative on value and gradient). */
 int oei_value_grad_warm_batched(oei_model* m, int B, int q, const double* X,
@@ -135,7 +139,10 @@ int oei_value_grad_warm_batched(oei_model* m, int B, int q, const double* X,
  * Limit: 3 * roundup(B*q, 64) * roundup(n, 64) + B*q*(1 + q + (d+1) * roundup(n,64)/64) doubles must
  * fit in OEI_NOALLOC_SCRATCH_DOUBLES (about 200 candidates at q = 20, n = 310); larger calls
  * return OEI_ERR_ARG with both numbers in oei_last_error().  All calls on one GPU share that
- * GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+ * GPU's array: calls that overlap on one GPU (different streams or threads) race.  The model's
+ * device must be the current device (OEI_ERR_ARG otherwise).  The per-device address table is
+ * filled without a lock by oei_model_create, or by the first call on a device: create the first
+ * model of each device (or make that first call) from one thread. */
 int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const double* X,
                                    double* value, double* grad, int* status, int* flags, void* stream);
 
@@ -147,6 +154,13 @@ int oei_value_grad_batched_noalloc(oei_model* m, int B, int q, const double* X,
  * oei_last_error(). */
 int oei_hessian_batched(oei_model* m, int B, int q, const double* X,
                         double* H, int* status, void* stream);
+
+/* The duplicate tests of `project` (oei.py:181-192) without an evaluation: flags device int[B]
+ * receives 1 where project would remove a point of candidate b (same two tests as the `flags` of
+ * oei_value_grad_batched), else 0.  acquisition_hessian returns zeros for such a candidate
+ * (oei.py:53-55); callers of oei_hessian_batched that want that behaviour mask its output with
+ * these flags. */
+int oei_project_flags(oei_model* m, int B, int q, const double* X, int* flags, void* stream);
 
 /* domega (oei.py:125-135): X device [B,q,d] -> domega device [B,k_,k_,q*d]. */
 int oei_domega_batched(oei_model* m, int B, int q, const double* X, double* domega, void* stream);
@@ -325,7 +339,8 @@ int oei_newton_init(int B, int n, const double* X0, const double* lower, const d
                     double* dws, int* iws, void* stream);
 /* ft [COUNTS[0]], gt [COUNTS[0], n]: objective and gradient at the rows of XC; Ht [COUNTS[1], n, n]:
  * Hessians at the rows of XH (non-finite entries count as zero; either list may be empty, its
- * pointers are then not read).  counts_host (int[2], optional): waits for the stream and returns
+ * pointers are then not read; a NULL ft/gt while runs wait for a trial value rejects those trial
+ * points, a NULL Ht while runs wait for a Hessian gives them a zero matrix -- no fault).  counts_host (int[2], optional): waits for the stream and returns
  * the new list lengths; both zero: all runs have stopped. */
 int oei_newton_advance(int B, int n, const double* ft, const double* gt, const double* Ht,
                        double pgtol, double ftol, double c1, int max_ls, int max_iter,

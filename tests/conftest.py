@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+    config.addinivalue_line('markers', 'gpu_slow: long GPU runs outside the round-end suite (run with -m gpu_slow)')
 
 
 @pytest.fixture(scope='session')

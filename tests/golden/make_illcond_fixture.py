@@ -1,0 +1,111 @@
+"""Regenerates tests/golden/illcond_rbf_*.npz: ill-conditioned RBF problems on which the device
+gradient and the fp64 CPU restatement differed by more than 1e-5 in the randomised sweep
+(tools/stress_parity.py, seed 7), arbitrated in extended precision (oracle/gp_mp.py, 256
+fractional bits).
+
+For each case the script replays the sweep's random stream to the case's inputs, then stores
+  * the inputs (training set, hyper-parameters, candidate batch),
+  * Omega and fmin in extended precision, rounded to fp64,
+  * value, M of the reference-form SDP solved on that Omega (oracle/sdp_ref.sdp_exact),
+  * the gradient d<Omega,M>/dX (oei.py:66-77) in extended precision and from the fp64
+    restatement with the same M, and the relative distance of the two,
+  * for the Hessian case: acquisition_hessian (oei.py:41-64) with every GP quantity in extended
+    precision, and the fp64 restatement's.
+
+Run from the repository root:  python tests/golden/make_illcond_fixture.py   (about ten minutes)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import gp as ogp, gp_mp, hart6, reduced_newton, sdp_ref   # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SEED = 7
+# case -> (candidate of the batch, with Hessian)
+CASES = {3967: (0, False), 3236: (0, False), 2858: (0, False), 296: (1, True)}
+
+
+def replay(seed, wanted):
+    """The sweep's draws, in its order (tools/stress_parity.py); yields the wanted cases."""
+    rs = np.random.RandomState(seed)
+    case = 0
+    last = max(wanted)
+    while case < last:
+        case += 1
+        q = int(rs.choice([1, 2, 3, 5, 8, 9, 13, 16, 17, 20, 24, 31, 32, 33, 41, 50, 64]))
+        d = int(rs.randint(1, 13))
+        n = int(rs.choice([3, 17, 63, 64, 65, 130, 310, 500]))
+        kind = int(rs.choice([ogp.KERNEL_RBF, ogp.KERNEL_MATERN32]))
+        fm = 0 if kind == ogp.KERNEL_RBF else int(rs.choice([1, 2]))
+        ls = float(rs.uniform(0.3, 1.0) * (1 + 0.05 * d))
+        noise = float(10.0 ** rs.uniform(-6, -2))
+        B = int(rs.choice([1, 2, 5]))
+        Xs = rs.uniform(-.5, .5, (B, q, d))
+        if q * d <= 400:
+            rs.randn(B, q * d)
+        if case in wanted:
+            yield case, dict(q=q, d=d, n=n, kind=kind, fm=fm, ls=ls, noise=noise, B=B, Xs=Xs)
+
+
+def solve_sdp(omega, fmin):
+    """Reference-form solve (first-order iterations + Newton polish on the reference's KKT system);
+    where its KKT matrix is singular at every checkpoint (constraints that are barely active), the
+    Newton iteration on the reduced dual.  Either way the caller certifies the result."""
+    try:
+        value, M, Y, _ = sdp_ref.sdp_exact(omega, fmin)
+        return value, M, Y, 'sdp_ref.sdp_exact'
+    except RuntimeError:
+        value, M, Y, _, _ = reduced_newton.solve(omega, fmin, tol=1e-9)
+        return value, M, Y, 'reduced_newton.solve'
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def main():
+    for case, c in replay(SEED, set(CASES)):
+        b, with_hess = CASES[case]
+        t0 = time.time()
+        om = hart6.make_model(c['n'], d=c['d'], train_seed=case, kind=c['kind'], floor_mode=c['fm'],
+                              lengthscale=c['ls'], noise=c['noise'])
+        kern = gp_mp.KernelMP(c['kind'], om.kernel.variance, om.kernel.lengthscales, c['d'],
+                              om.kernel.floor_mode)
+        mm = gp_mp.GPModelMP(om.X, om.y, kern, om.noise)
+        X = c['Xs'][b]
+        omega_mp = mm.omega(X)
+        value, M, Y, solver = solve_sdp(omega_mp, mm.fmin)
+        C = sdp_ref.create_C(omega_mp.shape[0], mm.fmin)
+        cert = sdp_ref._cert_max(sdp_ref.kkt_certificate(omega_mp, mm.fmin, M, Y))
+        _, g_mp = mm.inner_and_grad(X, M)
+        _, g_64 = om.inner_and_grad(X, M)
+        out = dict(case=case, seed=SEED, b=b, kind=c['kind'], floor_mode=om.kernel.floor_mode,
+                   variance=om.kernel.variance, lengthscales=om.kernel.lengthscales, noise=om.noise,
+                   X_train=om.X, y=om.y, X=X, fmin_mp=mm.fmin, fmin_fp64=om.fmin,
+                   omega_mp=omega_mp, omega_fp64=om.omega(X), value=value, M=M, kkt=cert, sdp_solver=solver,
+                   grad_mp=g_mp, grad_fp64=g_64, grad_fp64_err=rel(g_64, g_mp),
+                   cond_K=np.linalg.cond(om.L) ** 2)
+        msg = 'case %d b=%d q=%d d=%d n=%d noise=%.1e: cond(K) %.1e, omega fp64-vs-mp %.1e, ' \
+              'grad fp64-vs-mp %.1e, kkt %.1e (%s)' % (case, b, c['q'], c['d'], c['n'], c['noise'],
+                                                  out['cond_K'], rel(out['omega_fp64'], omega_mp),
+                                                  out['grad_fp64_err'], cert, solver)
+        if with_hess:
+            # oei.py:58-64 with the GP quantities from either model and the same (M, Y)
+            def hessian(model):
+                dom = model.domega(X)
+                dM = sdp_ref.solution_derivative(M, Y, C, dom)
+                return model.inner_hessian(X, M) + np.tensordot(np.transpose(dM), dom, axes=2)
+            H_mp, H_64 = hessian(mm), hessian(om)
+            out.update(hess_mp=H_mp, hess_fp64=H_64, hess_fp64_err=rel(H_64, H_mp))
+            msg += ', hessian fp64-vs-mp %.1e' % out['hess_fp64_err']
+        np.savez_compressed(os.path.join(HERE, 'illcond_rbf_%d.npz' % case), **out)
+        print(msg + ' (%.0f s)' % (time.time() - t0), flush=True)
+
+
+if __name__ == '__main__':
+    main()

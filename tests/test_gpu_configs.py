@@ -6,8 +6,9 @@
   cfg 5  the driver with the reference's flags (README.md:41): batch_size 20, initial_size 10,
          15 iterations, noise 1e-6
 
-cfg 4 (eight GPUs) is the same per-rank path as cfg 2 plus the record exchange, which the gloo
-tests cover; it needs an 8-GPU node.  Task bars: 1e-5 value, 1e-4 gradient, 1e-3 Hessian entries;
+cfg 4 (eight GPUs; 65 536 candidates, 8192 per rank, seed 3): every rank's shard is evaluated
+here, one after another on the one GPU, and the eight records are merged as the ranks would merge
+them; the all-gather itself runs once over RCCL in a group of one rank.  Task bars: 1e-5 value, 1e-4 gradient, 1e-3 Hessian entries;
 the assertions are tighter and say so.
 """
 import os
@@ -224,3 +225,68 @@ def test_select_record_matches_the_tensor_statement(cuda):
             win = int(torch.argmin(cand))
             out = engine.select_record(t.to(cuda)).cpu()
             assert out.numpy().tobytes() == t[win].numpy().tobytes()
+
+
+def test_cfg4_every_rank_shard_on_one_gpu(cuda):
+    """cfg 4 at its real size: the eight 8192-candidate shards of the 65 536-candidate array
+    (seed 3), each through `evaluate_and_select` with its global index base, as rank r would run
+    it.  Every candidate converges; a strided sample of 32 from the first and the last shard is
+    certified; the eight records merged by `oei_select_record` name the arg-min of all 65 536
+    values (ties to the lowest index) and carry that candidate's X bit for bit."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from bayesian_optimization_amd import engine, multistart
+    om, dm = _mk(310)
+    total, world, q, d = 65536, 8, 20, 6
+    records, values = [], []
+    for rank in range(world):
+        lo, hi = multistart.shard_bounds(total, world, rank)
+        assert hi - lo == 8192
+        Xs = bench.candidate_block(total, q, d, 3, lo, hi)
+        Xd = torch.as_tensor(Xs, device=cuda)
+        value, grad, status, best = multistart.evaluate_and_select(dm, Xd, index_base=lo)
+        assert int((status != 0).sum()) == 0
+        assert bool(torch.isfinite(value).all()) and bool(torch.isfinite(grad).all())
+        values.append(value.cpu().numpy())
+        records.append(multistart.make_record(best[0], best[1], best[2].reshape(-1)))
+        li = int(best[1].item()) - lo
+        assert 0 <= li < hi - lo and np.array_equal(best[2].cpu().numpy(), Xs[li])
+        if rank in (0, world - 1):
+            v_h, g_h = values[-1], grad.cpu().numpy()
+            for b in range(5, 8192, 512):                     # 16 per shard
+                _certify(om, dm, Xs[b], v_h[b], g_h[b], 1e-8)
+    allv = np.concatenate(values)
+    win = int(np.flatnonzero(allv == allv.min())[0])
+    row = engine.select_record(torch.stack(records))
+    assert int(row[1:2].view(torch.int64).item()) == win
+    assert float(row[0].item()) == allv[win]
+    lo, hi = multistart.shard_bounds(total, world, win // 8192)
+    assert np.array_equal(row[2:].cpu().numpy().reshape(q, d), bench.candidate_block(total, q, d, 3, lo, hi)[win - lo])
+
+
+def test_rccl_all_gather_in_a_group_of_one(cuda):
+    """`bench.py --gpus 1 --force-collective`: a process group of one rank on the nccl backend
+    (RCCL), the best-start record sent through `all_gather_into_tensor` on the device -- the call
+    an 8-GPU run depends on -- selects the start the run without a process group selects."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+    def bench(*flags):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1',
+                              '--no-cpu-baseline', '--no-hessian', '--seed', '3', '--batch', '512'] + list(flags),
+                             env=env, stdout=subprocess.PIPE, timeout=600, check=True).stdout.decode()
+        lines = [l for l in out.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, out
+        return json.loads(lines[0])
+
+    forced = bench('--force-collective')
+    plain = bench()
+    assert 'nccl' in forced['collective'] and plain['collective'] is None
+    assert forced['unconverged'] == 0
+    assert forced['best'] == plain['best']

@@ -5,6 +5,7 @@ import pickle
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import gp as ogp, hart6, nlml as onlml
 
@@ -167,3 +168,26 @@ def test_driver_end_to_end(cuda, tmp_path, monkeypatch):
     # same seed, same run
     run.main(args)
     assert np.array_equal(np.load(os.path.join('out', 'hart6_OEI', '7.npz'))['X'], X)
+
+
+def test_refactor_waits_for_evaluations_in_flight(cuda):
+    """oei_model_refactor rewrites the factors that evaluations read.  A large evaluation enqueued
+    on a non-default (non-blocking with respect to the null stream) torch stream right before a
+    refactorisation must still see the old factors: same bits as an evaluation that was waited
+    for, and the next evaluation sees the new ones."""
+    from bayesian_optimization_amd import DeviceGP
+    om = hart6.make_model(310)
+    dm = DeviceGP(om.X, om.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    Xd = torch.as_tensor(np.random.RandomState(4).uniform(-.5, .5, (4096, 20, 6)), device=cuda)
+    ref_old = dm.value_grad(Xd)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out = dm.value_grad(Xd)                 # asynchronous: about a millisecond of device work
+    dm.refactor(1.3, [0.7], 1e-6)               # must not overtake it
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref_old[0]) and torch.equal(out[1], ref_old[1])
+    new = dm.value_grad(Xd)
+    fresh = DeviceGP(om.X, om.y, ogp.KERNEL_MATERN32, 1.3, [0.7], 1e-6, floor_mode=1)
+    ref_new = fresh.value_grad(Xd)
+    assert torch.equal(new[0], ref_new[0]) and torch.equal(new[1], ref_new[1])

@@ -168,3 +168,28 @@ def test_lockstep_newton_consumes_batched_hessian(cuda):
     assert np.allclose(v.cpu().numpy(), r2.fun.cpu().numpy(), rtol=1e-12)
     pg = x - np.clip(x - g.cpu().numpy().reshape(B, -1), -0.5, 0.5)
     assert np.abs(pg).max() < 1e-3
+
+
+def test_newton_path_zeroes_the_hessian_of_duplicate_candidates(cuda):
+    """acquisition_hessian returns zeros when `project` would remove a point (oei.py:53-55).  The
+    batched Hessian adapter of the Newton path does the same from the device's duplicate flags,
+    and a multistart whose starts include a duplicate of a training point still ends finite."""
+    from bayesian_optimization_amd import DeviceGP, lockstep
+    q = 3
+    model = hart6.make_model(25)
+    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    starts = np.random.RandomState(3).uniform(-.5, .5, (6, q, 6))
+    starts[2, 1] = model.X[4] + 1e-4               # within 1e-2 lengthscales of a training input
+    starts[5, 2] = starts[5, 0] + 1e-6             # two equal points
+    hess = lockstep.acquisition_hess_fun(gp, q)
+    H = hess(torch.as_tensor(starts, device=gp.device).reshape(6, -1))
+    zero = (H == 0).all(dim=2).all(dim=1).cpu().numpy()
+    assert zero.tolist() == [False, False, True, False, False, True]
+    raw, st = gp.hessian(starts)
+    assert int((st != 0).sum()) == 0 and torch.equal(H[0], raw[0])
+
+    bo, _ = _make_oei(25, q, 'lockstep', 6)
+    res, best = lockstep.optimize_multistart(
+        gp, starts, [-0.5] * 6, [0.5] * 6, method='newton',
+        project_fallback=lambda x: (lambda r: (r[0][0], r[1]))(bo.acquisition(x)))
+    assert bool(torch.isfinite(res.fun).all()) and bool(torch.isfinite(best[0]))

@@ -132,6 +132,19 @@ def test_project_flags(cuda):
     Xs[3, 4] = Xs[3, 0] + 1e-5           # mutual duplicate
     flags = dm.value_grad(Xs)[3].cpu().numpy()
     assert flags.tolist() == [0, 1, 0, 1]
+    # the stand-alone duplicate test (what masks the Hessian of such a candidate) agrees, also on
+    # a batch that spans many workgroups and for q > 32
+    assert dm.project_flags(Xs).cpu().numpy().tolist() == [0, 1, 0, 1]
+    for q in (1, 20, 33):
+        Xb = rs.uniform(-.5, .5, (300, q, 6))
+        hit = rs.rand(300) < 0.3
+        for b in np.flatnonzero(hit):
+            if q > 1 and b % 2:
+                Xb[b, q - 1] = Xb[b, 0]          # (a small offset could straddle a rounding boundary of X/l)
+            else:
+                Xb[b, b % q] = om.X[b % 25] - 1e-4
+        assert np.array_equal(dm.project_flags(Xb).cpu().numpy() != 0, hit)
+        assert np.array_equal(dm.value_grad(Xb)[3].cpu().numpy() != 0, hit)
 
 
 def test_argmin_ties(cuda):

@@ -64,6 +64,34 @@ def test_sdp_nan_raises_and_failure_warns(cuda, caplog):
     assert 'SDP solution status' in caplog.text and np.isnan(val)
 
 
+def test_sdp_singular_psd_omega_is_served(cuda, caplog):
+    """The reference hands any symmetric Omega to SCS (sdp.py:34-67); a positive semidefinite but
+    singular one (two identical candidate points, no noise) has a finite optimum.  The device
+    solver needs a positive definite covariance block, so the shim retries on Omega + eps I and
+    warns: finite value, within 1e-5 of the first-order solve of the singular problem."""
+    from bayesian_optimization_amd.methods import sdp
+    rs = np.random.RandomState(5)
+    A = rs.randn(4, 3)
+    S = A @ A.T                                     # rank 3, 4 x 4
+    mu = rs.randn(4)
+    om = np.zeros((5, 5))
+    om[:4, :4] = S + np.outer(mu, mu)
+    om[:4, 4] = om[4, :4] = mu
+    om[4, 4] = 1.0
+    assert np.linalg.eigvalsh(om)[0] > -1e-12 and np.linalg.matrix_rank(om) == 4
+    with caplog.at_level('WARNING', logger='opt'):
+        val, M, Y, C = sdp.sdp(om, -0.3)
+    assert np.isfinite(val) and np.isfinite(M).all() and 'regularised' in caplog.text
+    # the reference's route: the singular matrix itself through the first-order cone solver
+    ref, _, _, _, info = sdp_ref.sdp_first_order(om, -0.3, eps=1e-7, max_iters=50000, return_info=True)
+    assert info['status'] == 'Solved' and abs(val - ref) <= 1e-5 * abs(ref)
+    # a matrix with a negative eigenvalue still warns and gives NaN
+    bad = om - 0.5 * np.eye(5)
+    with caplog.at_level('WARNING', logger='opt'):
+        val2 = sdp.sdp(bad, -0.3)[0]
+    assert np.isnan(val2)
+
+
 def test_sensitivity_like_reference_test(cuda):
     """tests/test_derivatives.py:82-112 with finite differences of the GPU solve itself."""
     from bayesian_optimization_amd.methods.sdp import sdp, solution_derivative
