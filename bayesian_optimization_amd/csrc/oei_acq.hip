@@ -246,8 +246,9 @@ __device__ __forceinline__ void zmat_mfma(const SdpWork w, int npad, size_t astr
 // mu [q+2] and xq [q*d].  `full`: six-matrix layout (sensitivity kernels), else three.
 __host__ __device__ inline size_t acq_stage_doubles(int q) { return (size_t)q * (CH + 1) + CH; }
 // `staged`: the 256-thread kernels stage A rows; the one-wave kernels read them through the MFMAs.
-__host__ __device__ inline size_t acq_lds_doubles(int q, int d, bool staged) {
-    return sdp_region_doubles(q, staged ? acq_stage_doubles(q) : 0, false) + (size_t)(q + 2) + (size_t)q * d;
+// `mm`: the instance keeps Lc^-T in a fourth matrix (sdp_mm<Q>()).
+__host__ __device__ inline size_t acq_lds_doubles(int q, int d, bool staged, bool mm = false) {
+    return sdp_region_doubles(q, staged ? acq_stage_doubles(q) : 0, false, mm) + (size_t)(q + 2) + (size_t)q * d;
 }
 
 // ---- omega (oei.py:79-96) ------------------------------------------------------------------------
@@ -299,8 +300,8 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     extern __shared__ __attribute__((aligned(16))) double sm[];
     OEI_LDS_POISON(sm);
     SdpWork w;
-    sdp_carve(w, sm, q, false);
-    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, Q == 0 ? acq_stage_doubles(q) : 0, false);
+    sdp_carve(w, sm, q, false, sdp_mm<Q>());
+    lds_f64* mu = (lds_f64*)sm + sdp_region_doubles(q, Q == 0 ? acq_stage_doubles(q) : 0, false, sdp_mm<Q>());
     lds_f64* xq = mu + q + 2;
     lds_f64* Ac = w.S;
     lds_f64* vc = Ac + q * (CH + 1);
@@ -672,7 +673,7 @@ int oei_launch_stage2(const oei_model* m, int B, int q, const double* X, const d
         return OEI_ERR_ARG;
     }
 #define LAUNCH_STAGE2(T_, Q_) do { \
-        const size_t lds2 = acq_lds_doubles(q, m->d, (Q_) == 0) * sizeof(double); \
+        const size_t lds2 = acq_lds_doubles(q, m->d, (Q_) == 0, sdp_mm<Q_>()) * sizeof(double); \
         if ((rc = set_lds(k_stage2<T_, Q_>, lds2))) return rc; \
         if (ev_start) /* the events take the kernel's own start and end from its dispatch */ \
             hipExtLaunchKernelGGL((k_stage2<T_, Q_>), dim3(B), dim3(T_), (uint32_t)lds2, st, ev_start, ev_stop, 0, m->kp, m->noise, m->fmin, m->n, m->npad, q, X, A, a_cand_stride, a_row_stride, (const double*)m->v, value, status, p_buf, M11_buf, Z, start_in, start_out, iters); \

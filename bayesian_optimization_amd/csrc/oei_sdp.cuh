@@ -54,15 +54,21 @@
 // 1e-7 costs one more direction and evaluation whose step is at rounding level.
 #define SDP_STEP_TOL 3e-6
 #define SDP_DECREMENT_TOL 1e-19
+#ifndef SDP_JACOBI_FINAL
 #define SDP_JACOBI_FINAL 1e-7
+#endif
 // evaluations that only steer the Newton iteration (every one but the last) stop earlier
 #define SDP_JACOBI_TOL_LOOSE 1e-11
+#ifndef SDP_JACOBI_FINAL_LOOSE
 #define SDP_JACOBI_FINAL_LOOSE 1e-5
+#endif
 #define SDP_EVAL_WARM 1
 #define SDP_EVAL_LOOSE 2
 // the very first evaluation feeds a step of several per cent: it may stop a sweep earlier
 #define SDP_EVAL_FIRST 4
+#ifndef SDP_JACOBI_FINAL_FIRST
 #define SDP_JACOBI_FINAL_FIRST 1e-3
+#endif
 
 // Inside one scheduling region: issue the LDS reads (up to nr) back to back, then the arithmetic,
 // and close the region.  Without this the register-pressure heuristic of the scheduler tends to
@@ -94,6 +100,7 @@ struct SdpWork {
     int q, LD;
     lds_f64 *H, *S, *X;                   // q x LD matrices, both layouts
     lds_f64 *V, *R, *Kt;                  // full layout only (sensitivity kernels)
+    lds_f64 *Li;                          // Lc^-T as a full matrix (instances with sdp_mm<Q>() only)
     lds_f64 *p, *pn, *s, *dl, *sq, *grad, *step, *tv, *sv, *rp, *ci, *ip, *wp;   // vectors
     lds_f64 *rc, *rs;                     // 1/diag(Lc) | 1/s
     lds_f64 *scal;                        // [8] scalars
@@ -103,25 +110,33 @@ struct SdpWork {
 __host__ __device__ inline int sdp_ld(int q) { return q | 1; }
 __host__ __device__ inline int sdp_vlen(int q) { return (q + 3) & ~1; }   // even, >= q + 2
 
-__host__ __device__ inline size_t sdp_work_doubles(int q, bool full) {
+// Instances of the register path that run their q x q products on the matrix pipe (template
+// parameter Q of the kernels; the host picks such an instance for every q <= 20): they keep
+// Lc^-T in a fourth q x q matrix.
+template <int Q> __host__ __device__ constexpr bool sdp_mm() { return Q > 0 && Q <= 20; }
+__host__ __device__ inline bool sdp_mm_q(int q) { return q <= 20; }
+
+__host__ __device__ inline size_t sdp_work_doubles(int q, bool full, bool mm = false) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
-    return (size_t)(full ? 6 : 3) * q * LD + (size_t)SDP_NVEC * VL + 8;
+    return (size_t)((full ? 6 : 3) + (mm ? 1 : 0)) * q * LD + (size_t)SDP_NVEC * VL + 8;
 }
 
 // Callers may use everything behind w.H (starting at w.S) as a staging buffer of `stage` doubles
 // while no solver state other than w.H is live.  Size of the region that must be reserved:
-__host__ __device__ inline size_t sdp_region_doubles(int q, size_t stage, bool full) {
-    const size_t h = (size_t)q * sdp_ld(q), rest = sdp_work_doubles(q, full) - h;
+__host__ __device__ inline size_t sdp_region_doubles(int q, size_t stage, bool full, bool mm = false) {
+    const size_t h = (size_t)q * sdp_ld(q), rest = sdp_work_doubles(q, full, mm) - h;
     return h + (rest > stage ? rest : stage);
 }
 
-__device__ inline void sdp_carve(SdpWork& w, double* base, int q, bool full) {
+__device__ inline void sdp_carve(SdpWork& w, double* base, int q, bool full, bool mm = false) {
     const int LD = sdp_ld(q), VL = sdp_vlen(q);
     w.q = q; w.LD = LD;
     lds_f64* ptr = (lds_f64*)base;
     w.H = ptr; ptr += q * LD;  w.S = ptr; ptr += q * LD;  w.X = ptr; ptr += q * LD;
     w.V = w.R = w.Kt = nullptr;
     if (full) { w.V = ptr; ptr += q * LD;  w.R = ptr; ptr += q * LD;  w.Kt = ptr; ptr += q * LD; }
+    w.Li = nullptr;
+    if (mm) { w.Li = ptr; ptr += q * LD; }
     w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
     w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
     w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;  w.ip = ptr; ptr += VL;
@@ -518,6 +533,33 @@ __device__ __forceinline__ int sdp_factor_reg(const SdpWork w) {
         for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.S[row * LD + k] = (k <= lane) ? a[k] : 0.0;
     }
     __syncthreads();
+    if constexpr (sdp_mm<Q>()) {
+        // Lc^-T as a full matrix (zeros below the diagonal) for the matrix-pipe product
+        // U = Lc^-T (G V) of every evaluation: lane j forms column j of Lc^-1 by forward
+        // substitution (x_k = 0 for k < j, so the sums need no bounds) and stores it as row j.
+        double x[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            if (EXACT || i < q) {
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) {
+                    const double l = w.S[i * LD + k];
+                    if (k & 1) acc1 = fma(l, x[k], acc1); else acc0 = fma(l, x[k], acc0);
+                }
+                const double rci = w.rc[i];
+                x[i] = (i == lane) ? rci : -(acc0 + acc1) * rci;
+                if (EXACT) { asm volatile("" : "+v"(x[i])); SDP_READS_FIRST(Q + 1, 2 * Q); }
+            } else {
+                x[i] = 0.0;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) if (EXACT || i < q) w.Li[row * LD + i] = (i >= lane) ? x[i] : 0.0;
+        }
+        __syncthreads();
+    }
     return fail;
 }
 
@@ -647,11 +689,21 @@ __device__ int sdp_jacobi_oe(double (&gt)[Q / 4], double (&gb)[Q / 4], double to
 
 // The evaluation with the pair-per-lane layout (every register-path size).  With `warm`, the state of the previous
 // evaluation (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in w.sv) seeds this one:
-// G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T); w.H is the transposition buffer.
-// Lane a ends up with column a of U in registers; the gradient needs rows of U (through LDS).
+// G <- G V_prev with V_prev = diag(1/s) (U + (gamma' p) sv^T).
+// Instances with sdp_mm<Q>() run the two q x q x q products of an evaluation -- the warm start
+// G V_prev and U = Lc^-T (G V) -- on the matrix pipe with the Jacobi registers as operands and
+// results: lane (part, kpos) holds the rows part, part + 4, part + 8, ... of its two columns, which
+// is the k position (l >> 4) + 4 s that v_mfma_f64_16x16x4 expects from lane l in its s-th step
+// and the row (l >> 4) + 4 g of its g-th accumulator, and tile J = 0 / 1 of the right operand is
+// the lane's top / bottom column.  Nothing of an evaluation goes through the exchange buffer then
+// (w.H keeps the Newton factor).  The other instances (Q = 32) keep rows RP part .. RP part + RP - 1
+// per lane, stage G through w.H and substitute with Lc, one column per lane.
 template <int Q, bool EXACT>
 __device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt, int& sweeps, int mode) {
     constexpr int RP = Q / 4, K = Q / 2;
+    constexpr bool MM = sdp_mm<Q>();
+    constexpr int NI = (Q + 15) / 16;                         // 16-row tiles of a q x q product
+    typedef double sdp_double4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x;
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     SDP_TIC(t_setup);
@@ -681,6 +733,7 @@ __device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt
     const double gam = sdp_rcp(1.0 + sp0), gamp = gam * rsp0;
     const double rsme = sdp_rsq(pme), sme = pme * rsme, ipme = rsme * rsme;
     const double rs_t = w.rs[ct], sv_t = w.sv[ct], rs_b = w.rs[cb], sv_b = w.sv[cb];   // read before this call overwrites them
+    const double rs_me = w.rs[me];
     const double pt_t = pt[ct], pt_b = pt[cb];
     __syncthreads();                    // earlier readers of the vectors are done
     {
@@ -693,16 +746,63 @@ __device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt
 #pragma unroll 4
             for (int i = 0; i < q; ++i) acc += w.S[i * LD + me] * pt[i];
         }
-        if (act) w.tv[tid] = acc;
+        if (act) {
+            w.tv[tid] = acc;
+            if constexpr (MM) w.ci[tid] = sme * rs_me;        // s_new / s_prev (warm start only)
+        }
     }
     __syncthreads();
-    lds_f64* GT = w.H;                  // q x q exchange buffer (w.H is free during an evaluation)
+    lds_f64* GT = w.H;                  // q x q exchange buffer of the instances without MM
     double gt[RP], gb[RP];
     int rr[RP];                         // this lane's rows, clamped; rows beyond q hold zeros
     bool rin[RP];
 #pragma unroll
-    for (int i = 0; i < RP; ++i) { rin[i] = EXACT || r0 + i < q; rr[i] = rin[i] ? r0 + i : 0; }
-    {   // rows r0.. of columns ct, cb of G = s_j (Lc^T e_j - gam m); idle lanes: zeros
+    for (int i = 0; i < RP; ++i) {
+        const int r = MM ? 4 * i + part : r0 + i;
+        rin[i] = EXACT || r < q;
+        rr[i] = rin[i] ? r : 0;
+    }
+    if (MM && (mode & SDP_EVAL_WARM)) {
+        // G V_prev = A B on the matrix pipe: A[r][j] = (s_j / s_prev_j) (Lc[j][r] - gam m_r),
+        // B[j][c] = U_prev[j][c] + wp_j sv_c.  Rows of A past q only reach rows of the product that
+        // nothing reads; columns of B past q and positions past K must be exact zeros (the Jacobi
+        // iteration relies on zero columns there).
+        sdp_double4 acc[NI][2];
+        double gm[NI];
+        int ra[NI];
+#pragma unroll
+        for (int I = 0; I < NI; ++I) {
+            acc[I][0] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+            acc[I][1] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+            const int r = 16 * I + kpos;
+            ra[I] = (r < q) ? r : 0;
+            gm[I] = gam * w.tv[ra[I]];
+        }
+#pragma unroll
+        for (int s = 0; s < RP; ++s) {
+            const int j = 4 * s + part;
+            const bool jin = EXACT || j < q;
+            const int jc = jin ? j : 0;
+            const double cj = w.ci[jc], wpj = w.wp[jc];
+            const double xt = w.X[jc * LD + ct], xb = w.X[jc * LD + cb];
+            double av[NI];
+#pragma unroll
+            for (int I = 0; I < NI; ++I) av[I] = cj * (w.S[jc * LD + ra[I]] - gm[I]);
+            const double bt = (ton && jin) ? fma(sv_t, wpj, xt) : 0.0;
+            const double bb = (bon && jin) ? fma(sv_b, wpj, xb) : 0.0;
+#pragma unroll
+            for (int I = 0; I < NI; ++I) {
+                acc[I][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bt, acc[I][0], 0, 0, 0);
+                acc[I][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bb, acc[I][1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            gt[i] = rin[i] ? acc[i / 4][0][i % 4] : 0.0;
+            gb[i] = rin[i] ? acc[i / 4][1][i % 4] : 0.0;
+        }
+    } else {
+        // rows of columns ct, cb of G = s_j (Lc^T e_j - gam m); idle lanes: zeros
         const double st = ton ? pt_t * sdp_rsq(pt_t) : 0.0, sb = bon ? pt_b * sdp_rsq(pt_b) : 0.0;
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
@@ -711,7 +811,7 @@ __device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt
             gb[i] = rin[i] ? sb * (w.S[cb * LD + rr[i]] - m) : 0.0;
         }
     }
-    if (mode & SDP_EVAL_WARM) {
+    if (!MM && (mode & SDP_EVAL_WARM)) {
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             if (ton && rin[i]) GT[rr[i] * LD + ct] = gt[i] * rs_t;
@@ -762,7 +862,7 @@ __device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt
     }
     SDP_TOC(1, t_jac);
     SDP_TIC(t_rest);
-    // singular values = column norms; U = Lc^-T (G V) by back substitution, one column per lane
+    // singular values = column norms; U = Lc^-T (G V)
     int bad = 0;
     double sqv = 0.0, su = 0.0;
     {
@@ -775,48 +875,92 @@ __device__ __forceinline__ double sdp_eval_oe(const SdpWork w, const lds_f64* pt
         const int ot = rev ? Q - 1 - 2 * kpos : 2 * kpos, ob = rev ? Q - 2 - 2 * kpos : 2 * kpos + 1;
         const bool wt = lane_on && (EXACT || ot < q), wb = lane_on && (EXACT || ob < q);
         if ((wt && !(n2t > 0.0)) || (wb && !(n2b > 0.0))) bad = 1;
-        // the columns go to LDS by column index, their singular values with them
+        if constexpr (MM) {
+            // U[k][c] = sum_r Lc^-T[k][r] (G V)[r][c]: the lane's s-th row is the k position of
+            // step s; Lc^-T[k][r] = 0 for r < k, so row tile I only needs the steps with 4 s + 3 >= 16 I
+            sdp_double4 u[NI][2];
+            int ka[NI];
 #pragma unroll
-        for (int i = 0; i < RP; ++i) {
-            if (wt && rin[i]) GT[rr[i] * LD + ot] = gt[i];
-            if (wb && rin[i]) GT[rr[i] * LD + ob] = gb[i];
-        }
-        if (part == 0) {
-            if (wt) w.sq[ot] = sqrt(fmax(n2t, 1e-300));
-            if (wb) w.sq[ob] = sqrt(fmax(n2b, 1e-300));
-        }
-        __syncthreads();
-        sqv = w.sq[me];
-        double g[Q], u[Q];
-#pragma unroll
-        for (int k = 0; k < Q; ++k) {
-            if (EXACT || k < q) g[k] = GT[k * LD + me];
-            else g[k] = 0.0;
-        }
-        if (EXACT) SDP_READS_FIRST(Q, Q);
-#pragma unroll
-        for (int k = Q - 1; k >= 0; --k) {
-            double acc = 0.0;
-            if (EXACT || k < q) {
-                acc = g[k];
-#pragma unroll
-                for (int r = k + 1; r < Q; ++r) if (EXACT || r < q) acc -= w.S[r * LD + k] * u[r];
-                acc *= w.rc[k];
+            for (int I = 0; I < NI; ++I) {
+                u[I][0] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+                u[I][1] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+                const int k = 16 * I + kpos;
+                ka[I] = (k < q) ? k : 0;
             }
-            asm volatile("" : "+v"(acc));      // keeps the arithmetic here (not sunk behind the loads)
-            u[k] = acc;
-            su += acc;
-            if (EXACT) SDP_READS_FIRST(Q, 2 * Q);
-        }
-        if (act) {
-            w.sv[tid] = su; w.rp[tid] = su * ip0;
-            w.s[tid] = sme; w.rs[tid] = rsme; w.ip[tid] = ipme; w.wp[tid] = gamp * pme;
 #pragma unroll
-            for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
+            for (int s = 0; s < RP; ++s) {
+#pragma unroll
+                for (int I = 0; I < NI; ++I) {
+                    if (4 * s + 3 < 16 * I) continue;
+                    const double a = w.Li[ka[I] * LD + rr[s]];          // rows of G V past q are zeros
+                    u[I][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gt[s], u[I][0], 0, 0, 0);
+                    u[I][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, gb[s], u[I][1], 0, 0, 0);
+                }
+            }
+            double st_ = 0.0, sb_ = 0.0;
+#pragma unroll
+            for (int I = 0; I < NI; ++I)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (16 * I + 4 * g >= Q) continue;
+                    const int k = 16 * I + part + 4 * g;
+                    if (EXACT || k < q) {
+                        st_ += u[I][0][g]; sb_ += u[I][1][g];
+                        if (wt) w.X[k * LD + ot] = u[I][0][g];
+                        if (wb) w.X[k * LD + ob] = u[I][1][g];
+                    }
+                }
+            st_ = sdp_rowsum4(st_); sb_ = sdp_rowsum4(sb_);
+            if (part == 0) {
+                if (wt) { w.sq[ot] = sqrt(fmax(n2t, 1e-300)); w.sv[ot] = st_; w.rp[ot] = st_ * ip0; }
+                if (wb) { w.sq[ob] = sqrt(fmax(n2b, 1e-300)); w.sv[ob] = sb_; w.rp[ob] = sb_ * ip0; }
+            }
+            if (act) { w.s[tid] = sme; w.rs[tid] = rsme; w.ip[tid] = ipme; w.wp[tid] = gamp * pme; }
+        } else {
+            // the columns go to LDS by column index, their singular values with them
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                if (wt && rin[i]) GT[rr[i] * LD + ot] = gt[i];
+                if (wb && rin[i]) GT[rr[i] * LD + ob] = gb[i];
+            }
+            if (part == 0) {
+                if (wt) w.sq[ot] = sqrt(fmax(n2t, 1e-300));
+                if (wb) w.sq[ob] = sqrt(fmax(n2b, 1e-300));
+            }
+            __syncthreads();
+            double g[Q], u[Q];
+#pragma unroll
+            for (int k = 0; k < Q; ++k) {
+                if (EXACT || k < q) g[k] = GT[k * LD + me];
+                else g[k] = 0.0;
+            }
+            if (EXACT) SDP_READS_FIRST(Q, Q);
+#pragma unroll
+            for (int k = Q - 1; k >= 0; --k) {         // back substitution, one column per lane
+                double acc = 0.0;
+                if (EXACT || k < q) {
+                    acc = g[k];
+#pragma unroll
+                    for (int r = k + 1; r < Q; ++r) if (EXACT || r < q) acc -= w.S[r * LD + k] * u[r];
+                    acc *= w.rc[k];
+                }
+                asm volatile("" : "+v"(acc));      // keeps the arithmetic here (not sunk behind the loads)
+                u[k] = acc;
+                su += acc;
+                if (EXACT) SDP_READS_FIRST(Q, 2 * Q);
+            }
+            if (act) {
+                w.sv[tid] = su; w.rp[tid] = su * ip0;
+                w.s[tid] = sme; w.rs[tid] = rsme; w.ip[tid] = ipme; w.wp[tid] = gamp * pme;
+#pragma unroll
+                for (int k = 0; k < Q; ++k) if (EXACT || k < q) w.X[k * LD + tid] = u[k];
+            }
         }
     }
     bad = __syncthreads_or(bad);
     if (bad) return -INFINITY;
+    sqv = w.sq[me];
+    if constexpr (MM) su = w.sv[me];
     {   // grad_i = (sum_a sq_a U_ia^2) / (2 p_i^2) - (sum_a sq_a rp_a^2)/2 - delta_i: lane i walks row i of U
         double d = 0.0;
         if constexpr (EXACT) {

@@ -11,8 +11,8 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_sdp_omega(int q, const 
     extern __shared__ __attribute__((aligned(16))) double sm[];
     OEI_LDS_POISON(sm);
     SdpWork w;
-    sdp_carve(w, sm, q, false);
-    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, false);  // [q]
+    sdp_carve(w, sm, q, false, sdp_mm<Q>());
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, false, sdp_mm<Q>());  // [q]
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     const int k_ = q + 1, LD = w.LD;
@@ -92,7 +92,7 @@ extern "C" int oei_sdp_batched(int B, int k_, const double* omega, const double*
     const int q = k_ - 1;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_SDP(T_, Q_) do { \
-        const size_t lds = (sdp_work_doubles(q, false) + q + 2) * sizeof(double); \
+        const size_t lds = (sdp_work_doubles(q, false, sdp_mm<Q_>()) + q + 2) * sizeof(double); \
         if (lds > 48 * 1024) OEI_HIP_CHECK(hipFuncSetAttribute((const void*)k_sdp_omega<T_, Q_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_sdp_omega<T_, Q_>), dim3(B), dim3(T_), lds, st, q, omega, fmin, value, M, Y, status, iters); } while (0)
     SDP_DISPATCH_Q(q, LAUNCH_SDP);

@@ -62,21 +62,26 @@ def flops_model(q, n, npad, newton_iters, sweeps):
     return moments + zmat + factor + evals * per_eval + sweeps * per_sweep + newton_iters * per_dir
 
 
-def hessian_flops_model(q, d, n, npad, sdp_flops):
+def hessian_flops_model(q, d, n, npad, sdp_flops, executed=False):
     """Algorithmic flops of one acquisition Hessian (fma = 2 flops), q <= 32 path:
-      front     RP = q(d+1)+1 rows (values, d derivative components, y; padded to 64) through the
-                triangular GEMM with L^-1 (K range of a 64-column tile stops at its diagonal), then
-                the Gram matrix of the block (lower block triangle, n-length sums)
+      front     q(d+1)+1 data rows (values, d derivative components, y) through the triangular GEMM
+                with L^-1 (K range of a 64-column tile stops at its diagonal), then the Gram matrix
+                of the block (lower triangle, n-length sums)
       solve     the SDP solve of the value+gradient path (`sdp_flops`) plus W = Z L^-1
       dirs      the table U^T v' of every direction (q d rows of q^2 multiply-adds), then q d
                 directions: three q^3 products (the direction stops at Y = U Z), about 12 q^2 for
                 the vector passes and the two triangular solves, and the contraction of the
                 direction's row with every dOmega_(b,m): q d (2 q + 30)
-    """
-    RP = -(-(q * (d + 1) + 1) // 64) * 64
+    Useful work only: the rows that carry data.  `executed` counts what the kernels multiply
+    instead -- blocks padded to a multiple of 64 rows, whole 64 x 64 tiles of the block Gram matrix."""
+    rows = q * (d + 1) + 1
     nt = npad // 64
     tri = 64 * 64 * nt * (nt + 1)                      # per row: column tile j takes 64 * 64 (j + 1) multiply-adds
-    front = RP * tri + (RP // 64) * (RP // 64 + 1) // 2 * 2 * 64 * 64 * npad
+    if executed:
+        RP = -(-rows // 64) * 64
+        front = RP * tri + (RP // 64) * (RP // 64 + 1) // 2 * 2 * 64 * 64 * npad
+    else:
+        front = rows * tri + rows * (rows + 1) * npad  # Gram: rows (rows + 1) / 2 sums of npad multiply-adds
     solve = sdp_flops + q * tri
     qd = q * d
     dirs = qd * 2 * q * q + qd * (6 * q ** 3 + 12 * q * q) + qd * qd * (2 * q + 30)
@@ -322,13 +327,16 @@ def main():
                 torch.cuda.synchronize()
                 th = (time.perf_counter() - th) / hreps
                 hfl = hessian_flops_model(q, d, n, gp.n + (-gp.n) % 64, fl / B)
+                hfl_exec = hessian_flops_model(q, d, n, gp.n + (-gp.n) % 64, fl / B, executed=True)
                 hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
                            'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item()),
                            'roofline': {'bound': 'fp64 (MFMA front end, vector-unit directions)',
-                                        'flops_per_hessian': hfl, 'achieved': hfl * hb / th / 1e12,
+                                        'flops_per_hessian': hfl, 'flops_per_hessian_executed': hfl_exec,
+                                        'achieved': hfl * hb / th / 1e12,
                                         'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                         'frac': hfl * hb / th / 1e12 / FP64_PEAK_TFLOPS,
-                                        'note': 'whole call (8 launches), wall clock over %d calls' % hreps}}
+                                        'note': 'whole call (8 launches), wall clock over %d calls; flops of the rows that '
+                                                'carry data (the executed count includes the padding of a block to whole tiles)' % hreps}}
             if not args.no_hessian and world == 1:
                 # the callers of the path, outside the timed region: 2048 multistart descents
                 # through the device optimiser, and a hyper-parameter fit with 20 restarts

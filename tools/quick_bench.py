@@ -25,3 +25,20 @@ print('stages ms: gram %.4f gemm1 %.4f stage2 %.4f gemm2 %.4f fin %.4f  total %.
 print('newton %.3f sweeps %.3f unsolved %d' % ((it & 0xffff).double().mean(), (it >> 16).double().mean(), int((status != 0).sum())))
 print('checksum value %s grad %s' % (hashlib.sha1(v.cpu().numpy().tobytes()).hexdigest()[:12], hashlib.sha1(g.cpu().numpy().tobytes()).hexdigest()[:12]))
 print('value[:3]', v[:3].tolist())
+
+if len(sys.argv) > 2:      # accuracy against the CPU restatement on a few candidates
+    from oracle import reduced_newton, sdp_ref
+    from bayesian_optimization_amd import sdp_batched
+    Xh = X[:int(sys.argv[2])].cpu().numpy()
+    omg = gp.omega(Xh)
+    v2, M, Y, st2, _ = [t.cpu().numpy() for t in sdp_batched(omg, gp.fmin)]
+    ev = eg = ec = 0.0
+    for b in range(Xh.shape[0]):
+        o = omg[b].cpu().numpy()
+        cert = sdp_ref.kkt_certificate(o, gp.fmin, M[b], list(Y[b]))
+        ec = max(ec, max(x for k, x in cert.items() if k not in ('pobj', 'dobj')))
+        obj = reduced_newton.solve(o, gp.fmin)[0]
+        ev = max(ev, abs(float(v[b]) - obj) / abs(obj))
+        _, g0 = model.inner_and_grad(Xh[b], M[b])
+        eg = max(eg, np.abs(g[b].cpu().numpy() - g0).max() / np.abs(g0).max())
+    print('accuracy on %d candidates: value %.1e gradient %.1e KKT %.1e' % (Xh.shape[0], ev, eg, ec))
