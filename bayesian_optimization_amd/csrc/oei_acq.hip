@@ -12,6 +12,12 @@
 
 #define CH 64            // training-point chunk staged in LDS
 #define ITEMS_MAX 10     // per-thread accumulators in the chunked reductions
+#ifndef OEI_PF
+#define OEI_PF 4
+#endif
+#ifndef OEI_PFZ
+#define OEI_PFZ 4
+#endif
 
 // Posterior moments of candidate b into LDS: w.S = Sigma + noise I (full, symmetric), mu[].
 // xq [q][d] must already be in LDS.  Ac is a [q][CH+1] staging buffer, vc a [CH] one.
@@ -127,36 +133,46 @@ __device__ __forceinline__ void posterior_moments_mfma(const SdpWork w, const Ke
     for (int I = 0; I < NR; ++I) {
         const int r = 16 * I + li;
         valid[I] = r <= q;
+        // rows past q read v as well: their products only reach entries of E E^T that nothing reads
         src[I] = (r < q ? Arows + (size_t)r * astride : v) + 4 * kg;
     }
     double4_t acc[NTILE];
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    double4_t cur[NR], nxt[NR];
-#pragma unroll
-    for (int I = 0; I < NR; ++I) {
-        cur[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        nxt[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        if (valid[I]) cur[I] = *reinterpret_cast<const double4_t*>(src[I]);
-    }
+    // A ring of PF column groups in flight: the rows come from HBM / L2 with a latency of a few
+    // microseconds under load, against well under a microsecond of matrix work per group, so one
+    // group ahead (as in the first version) left the wave waiting for most of this phase.
+    // The loads are unconditional (groups past the end re-read the last one): with a branch around
+    // them the compiler can no longer count the loads in flight and waits for all of them.
+    constexpr int PF = OEI_PF;                    // npad is a multiple of 64, so ns is one of PF = 4
+    double4_t ring[PF][NR];
     const int ns = npad / 16;
-    for (int s = 0; s < ns; ++s) {
-        if (s + 1 < ns) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int I = 0; I < NR; ++I) {
+            ring[u][I] = *reinterpret_cast<const double4_t*>(src[I] + 16 * u);
+        }
+    for (int s0 = 0; s0 < ns; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            double4_t cur[NR];
+#pragma unroll
+            for (int I = 0; I < NR; ++I) cur[I] = ring[u][I];
+            const int sn = min(s0 + u + PF, ns - 1);
 #pragma unroll
             for (int I = 0; I < NR; ++I)
-                if (valid[I]) nxt[I] = *reinterpret_cast<const double4_t*>(src[I] + 16 * (s + 1));
+                ring[u][I] = *reinterpret_cast<const double4_t*>(src[I] + 16 * sn);
+#pragma unroll
+            for (int v4 = 0; v4 < 4; ++v4) {
+                int t = 0;
+#pragma unroll
+                for (int I = 0; I < NR; ++I)
+#pragma unroll
+                    for (int J = 0; J <= I; ++J, ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][v4], cur[J][v4], acc[t], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int t = 0;
-#pragma unroll
-            for (int I = 0; I < NR; ++I)
-#pragma unroll
-                for (int J = 0; J <= I; ++J, ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][u], cur[J][u], acc[t], 0, 0, 0);
-        }
-#pragma unroll
-        for (int I = 0; I < NR; ++I) cur[I] = nxt[I];
     }
     // accumulator g of lane l is entry (row (l >> 4) + 4 g, column l & 15) of its tile
     {
@@ -218,26 +234,40 @@ __device__ __forceinline__ void zmat_mfma(const SdpWork w, int npad, size_t astr
         bval[s] = b < q;
         brow[s] = Arows + (size_t)(bval[s] ? b : 0) * astride + li;
     }
-#pragma unroll 2
-    for (int c0 = 0; c0 < npad; c0 += 16) {
-        double bop[NKZ];
+    // PFZ column groups of the A rows in flight (see posterior_moments_mfma)
+    constexpr int PFZ = OEI_PFZ;                  // npad / 16 is a multiple of PFZ = 4
+    double ring[PFZ][NKZ];
+    const int ng = npad / 16;
 #pragma unroll
-        for (int s = 0; s < NKZ; ++s) { const double x = brow[s][c0]; bop[s] = bval[s] ? x : 0.0; }
-        double4_t acc[NRZ];
+    for (int u = 0; u < PFZ; ++u)
 #pragma unroll
-        for (int I = 0; I < NRZ; ++I) acc[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < NKZ; ++s) ring[u][s] = brow[s][16 * u];
+    for (int g0 = 0; g0 < ng; g0 += PFZ) {
 #pragma unroll
-        for (int s = 0; s < NKZ; ++s)
+        for (int u = 0; u < PFZ; ++u) {
+            const int c0 = 16 * (g0 + u);
+            double bop[NKZ];
+#pragma unroll
+            for (int s = 0; s < NKZ; ++s) bop[s] = bval[s] ? ring[u][s] : 0.0;
+            const int cn = 16 * min(g0 + u + PFZ, ng - 1);
+#pragma unroll
+            for (int s = 0; s < NKZ; ++s) ring[u][s] = brow[s][cn];
+            double4_t acc[NRZ];
+#pragma unroll
+            for (int I = 0; I < NRZ; ++I) acc[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < NKZ; ++s)
+#pragma unroll
+                for (int I = 0; I < NRZ; ++I)
+                    acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(nop[I][s], bop[s], acc[I], 0, 0, 0);
 #pragma unroll
             for (int I = 0; I < NRZ; ++I)
-                acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(nop[I][s], bop[s], acc[I], 0, 0, 0);
 #pragma unroll
-        for (int I = 0; I < NRZ; ++I)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = 16 * I + kg + 4 * g;
-                if (row < q) Zrows[(size_t)row * npad + c0 + li] = -acc[I][g];
-            }
+                for (int g = 0; g < 4; ++g) {
+                    const int row = 16 * I + kg + 4 * g;
+                    if (row < q) Zrows[(size_t)row * npad + c0 + li] = -acc[I][g];
+                }
+        }
     }
 }
 
@@ -309,8 +339,14 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
     const double* Arows = A + (size_t)b * a_cand_stride;
+#ifdef OEI_SDP_TIMING
+    const long long tk0 = clock64();
+#endif
     if constexpr (Q > 0) posterior_moments_mfma<Q>(w, kp, noise, npad, a_row_stride, Arows, v, xq, mu);
     else posterior_moments<T>(w, kp, noise, n, npad, a_row_stride, Arows, v, xq, mu, Ac, vc);
+#ifdef OEI_SDP_TIMING
+    const long long tk1 = clock64();
+#endif
     if (tid < q) w.dl[tid] = mu[tid] - fmin;
     __syncthreads();
     double g = 0.0;
@@ -326,7 +362,13 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
         for (int e = tid; e < q * npad; e += T) Zrows[e] = NAN;
         return;
     }
+#ifdef OEI_SDP_TIMING
+    const long long tk2 = clock64();
+#endif
     sdp_primal<T>(w, mu);       // N = B^-1 in w.H
+#ifdef OEI_SDP_TIMING
+    const long long tk3 = clock64();
+#endif
     if (tid == 0) { value[b] = -g; status[b] = st; }
     for (int e = tid; e < q; e += T) p_out[(size_t)b * q + e] = w.p[e];
     for (int e = tid; e < q * q; e += T) {
@@ -353,6 +395,19 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
             }
         }
     }
+#ifdef OEI_SDP_TIMING
+    // diagnostic build: cycles of [moments, solve, primal, outputs + Z] and the solver's own
+    // phase counters in place of the start state
+    if (start_out) {
+        __syncthreads();
+        const long long tk4 = clock64();
+        double* so = start_out + (size_t)b * q;
+        if (tid == 0 && q >= 12) {
+            so[0] = (double)(tk1 - tk0); so[1] = (double)(tk2 - tk1); so[2] = (double)(tk3 - tk2); so[3] = (double)(tk4 - tk3);
+            for (int i = 0; i < 8; ++i) so[4 + i] = w.scal[i];
+        }
+    }
+#endif
 }
 
 // ---- gradient -------------------------------------------------------------------------------------

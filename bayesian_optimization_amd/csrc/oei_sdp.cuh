@@ -503,7 +503,9 @@ __device__ __forceinline__ int sdp_chol_rows(double (&a)[Q], double& dinv, int q
             for (int j = k + 1; j < Q; ++j) {
                 if (EXACT || j < q) { const double ljk = sdp_lane_bcast(lik, j); a[j] -= lik * ljk; }
             }
+#ifndef SDP_CHOL_NO_BARRIER
             if (EXACT) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     }
     return fail;
@@ -1627,14 +1629,53 @@ __device__ double sdp_primal(const SdpWork w, const lds_f64* mu) {
         w.step[tid] = 0.5 / w.sq[tid];
     }
     __syncthreads();
-    for (int e = tid; e < q * q; e += T) {
-        const int i = e / q, j = e - i * q;
-        if (j > i) continue;
-        double acc = 0.0;
+    if (T == 64 && q <= 32) {
+        // one wave: N = U diag(1/(2 sq)) U^T on the matrix pipe, lower tiles (0,0), (1,0), (1,1),
+        // mirrored on the way out.  Lane l supplies row 16 I + (l & 15) at k position 4 s + (l >> 4).
+        typedef double sdp_double4 __attribute__((ext_vector_type(4)));
+        const int li = tid & 15, kg = tid >> 4;
+        const bool two = q > 16;                           // uniform
+        sdp_double4 acc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+        const int i0 = li, i1 = 16 + li;
+        const bool v0 = i0 < q, v1 = i1 < q;
+        const lds_f64* u0 = U + (v0 ? i0 : 0) * LD;
+        const lds_f64* u1 = U + (v1 ? i1 : 0) * LD;
+        const int ks = (q + 3) >> 2;
+        for (int st = 0; st < ks; ++st) {
+            const int a = 4 * st + kg;
+            const bool ain = a < q;
+            const int ac = ain ? a : 0;
+            const double wa = w.step[ac];
+            const double x0 = u0[ac], x1 = u1[ac];
+            const double b0 = (v0 && ain) ? x0 : 0.0, b1 = (v1 && ain) ? x1 : 0.0;
+            const double a0 = b0 * wa, a1 = b1 * wa;
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+            if (two) {
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[2], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r0 = kg + 4 * g, r1 = 16 + kg + 4 * g, c0 = li, c1 = 16 + li;
+            if (r0 < q && c0 <= r0) { w.H[r0 * LD + c0] = acc[0][g]; w.H[c0 * LD + r0] = acc[0][g]; }
+            if (two) {
+                if (r1 < q && c0 < q) { w.H[r1 * LD + c0] = acc[1][g]; w.H[c0 * LD + r1] = acc[1][g]; }
+                if (r1 < q && c1 <= r1) { w.H[r1 * LD + c1] = acc[2][g]; w.H[c1 * LD + r1] = acc[2][g]; }
+            }
+        }
+    } else {
+        for (int e = tid; e < q * q; e += T) {
+            const int i = e / q, j = e - i * q;
+            if (j > i) continue;
+            double acc = 0.0;
 #pragma unroll 4
-        for (int a = 0; a < q; ++a) acc += U[i * LD + a] * U[j * LD + a] * w.step[a];
-        w.H[i * LD + j] = acc;
-        w.H[j * LD + i] = acc;
+            for (int a = 0; a < q; ++a) acc += U[i * LD + a] * U[j * LD + a] * w.step[a];
+            w.H[i * LD + j] = acc;
+            w.H[j * LD + i] = acc;
+        }
     }
     __syncthreads();
     if (tid < q) {

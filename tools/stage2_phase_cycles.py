@@ -1,0 +1,19 @@
+"""Diagnostic (timing build only, see tools/sdp_phase_cycles.sh): cycles one wave of k_stage2 spends in
+the posterior moments, the SDP solve, the primal matrix and the outputs + Z, at the benchmark's shape."""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bayesian_optimization_amd import DeviceGP
+from oracle import hart6, gp as ogp
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+model = hart6.make_model(310)
+gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+gp.set_pipelining(False)
+X = np.random.RandomState(1).uniform(-.5, .5, (B, 20, 6))
+for _ in range(3):
+    out = gp.value_grad_warm(X)
+c = out[4].cpu().numpy()
+names = ['moments', 'solve', 'primal', 'outputs + Z', ' eval set-up', ' jacobi', ' eval rest', ' newton dir', '  hess items', '  cholesky']
+for nm, v in zip(names, c[:, :10].mean(axis=0)):
+    print('%-14s %9.0f cycles' % (nm, v))
+print('kernel total   %9.0f cycles per wave' % c[:, :4].sum(axis=1).mean())
