@@ -60,6 +60,13 @@ SIGNATURES = {
     'oei_newton_advance': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp,
                                           ctypes.POINTER(ctypes.c_int), vp]),
+    'oei_multistart_workspace': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]),
+    'oei_lbfgs_minimize_rounds': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                 ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_int), vp]),
+    'oei_newton_minimize_rounds': (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                                  ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.POINTER(ctypes.c_int), vp]),
     'oei_model_nlml': (ctypes.c_int, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
 }
 

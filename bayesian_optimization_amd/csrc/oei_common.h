@@ -165,3 +165,20 @@ int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, 
                          double* Gpart, size_t nrows, size_t rows_pad, hipStream_t st);
 int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,
                        int lower, hipStream_t st);
+
+// ---- multistart state machines: launches of one advance and addresses inside their workspaces
+// (oei_lbfgs.hip, oei_newton.hip), for the round drivers of oei_multistart.hip ----------------------
+int oei_lbfgs_advance_launch(int B, int n, int history, const double* ft, const double* gt,
+                             const int* tstatus, const int* tflags, int* flagged,
+                             double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                             double* dws, int* iws, hipStream_t st);
+int* oei_lbfgs_count_ptr(int B, int n, int history, double* dws, int* iws);
+double* oei_lbfgs_list_ptr(int B, int n, int history, double* dws, int* iws);
+int oei_newton_advance_launch(int B, int n, const double* ft, const double* gt, const double* Ht,
+                              const int* tstatus, const int* tflags, int* flagged,
+                              double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                              double* dws, int* iws, hipStream_t st);
+int* oei_newton_counts_ptr(int B, int n, double* dws, int* iws);
+double* oei_newton_trial_list_ptr(int B, int n, double* dws, int* iws);
+double* oei_newton_hess_list_ptr(int B, int n, double* dws, int* iws);
+int oei_newton_check_shape(const char* who, int B, int n);

@@ -91,17 +91,27 @@ __global__ __launch_bounds__(64) void k_lbfgs_init(LbfgsView V, const double* __
 // One wave per run.  Every running run has exactly one evaluation outstanding (row rowof[r] of
 // ft / gt): the value and gradient at xt.  Lane l owns the vector elements l, l + 64, ..., so a
 // vector written by this wave is read back by the lanes that wrote it.
+// tstatus (optional, per list row): a non-zero entry makes the row's value +inf (an evaluation that
+// did not solve is a rejected trial point).  tflags (optional, per list row) with `flagged`: a run
+// whose row is flagged is left exactly as it is -- its trial point stays in the next list -- and
+// counted, so that the caller can evaluate that point another way and advance again.
 __global__ __launch_bounds__(64) void k_lbfgs_step(LbfgsView V, const double* __restrict__ ft,
                                                    const double* __restrict__ gt, double pgtol, double ftol,
-                                                   double c1, int max_ls, int max_iter) {
+                                                   double c1, int max_ls, int max_iter,
+                                                   const int* __restrict__ tstatus, const int* __restrict__ tflags,
+                                                   int* __restrict__ flagged) {
     const int r = blockIdx.x, lane = threadIdx.x, n = V.n, m = V.m;
-    if (lane == 0) V.need[r] = 0;
-    if (V.status[r] != ST_RUNNING) return;
+    if (V.status[r] != ST_RUNNING) { if (lane == 0) V.need[r] = 0; return; }
     const size_t o = (size_t)r * n;
     double* x = V.x + o; double* g = V.g + o; double* d = V.d + o; double* xt = V.xt + o;
     const double* lo = V.lo; const double* hi = V.hi;
     const int c = V.rowof[r];
-    const double fv = ft[c];
+    if (tflags && tflags[c]) {
+        if (lane == 0) { V.need[r] = 1; atomicAdd(flagged, 1); }
+        return;
+    }
+    if (lane == 0) V.need[r] = 0;
+    const double fv = (tstatus && tstatus[c] != 0) ? INFINITY : ft[c];
     const double* gn = gt + (size_t)c * n;
     const int nfev = V.nfev[r] + 1;
     if (lane == 0) V.nfev[r] = nfev;
@@ -300,6 +310,24 @@ extern "C" int oei_lbfgs_init(int B, int n, int history, const double* X0, const
     return OEI_OK;
 }
 
+// The launches of one advance; tstatus / tflags / flagged as in k_lbfgs_step (all optional).
+int oei_lbfgs_advance_launch(int B, int n, int history, const double* ft, const double* gt,
+                             const int* tstatus, const int* tflags, int* flagged,
+                             double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                             double* dws, int* iws, hipStream_t st) {
+    LbfgsView V = make_view(B, n, history, dws, iws);
+    hipLaunchKernelGGL(k_lbfgs_step, dim3(B), dim3(64), 0, st, V, ft, gt, pgtol, ftol, c1, max_ls, max_iter,
+                       tstatus, tflags, flagged);
+    hipLaunchKernelGGL(k_lbfgs_compact, dim3(1), dim3(1024), 0, st, V);
+    hipLaunchKernelGGL(k_lbfgs_gather, dim3(B), dim3(64), 0, st, V);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+// device address of COUNT and of the list XC inside the workspaces
+int* oei_lbfgs_count_ptr(int B, int n, int history, double* dws, int* iws) { return make_view(B, n, history, dws, iws).count; }
+double* oei_lbfgs_list_ptr(int B, int n, int history, double* dws, int* iws) { return make_view(B, n, history, dws, iws).Xc; }
+
 extern "C" int oei_lbfgs_advance(int B, int n, int history, const double* ft, const double* gt,
                                  double pgtol, double ftol, double c1, int max_ls, int max_iter,
                                  double* dws, int* iws, int* count_host, void* stream) {
@@ -308,13 +336,11 @@ extern "C" int oei_lbfgs_advance(int B, int n, int history, const double* ft, co
     if (!ft || !gt || !dws || !iws) { oei_set_error("lbfgs_advance: null pointer"); return OEI_ERR_ARG; }
     if (max_ls < 1 || max_iter < 0) { oei_set_error("lbfgs_advance: max_ls >= 1 and max_iter >= 0 required"); return OEI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    LbfgsView V = make_view(B, n, history, dws, iws);
-    hipLaunchKernelGGL(k_lbfgs_step, dim3(B), dim3(64), 0, st, V, ft, gt, pgtol, ftol, c1, max_ls, max_iter);
-    hipLaunchKernelGGL(k_lbfgs_compact, dim3(1), dim3(1024), 0, st, V);
-    hipLaunchKernelGGL(k_lbfgs_gather, dim3(B), dim3(64), 0, st, V);
-    OEI_HIP_CHECK(hipGetLastError());
+    const int lrc = oei_lbfgs_advance_launch(B, n, history, ft, gt, nullptr, nullptr, nullptr, pgtol, ftol, c1,
+                                             max_ls, max_iter, dws, iws, st);
+    if (lrc) return lrc;
     if (count_host) {
-        OEI_HIP_CHECK(hipMemcpyAsync(count_host, V.count, sizeof(int), hipMemcpyDeviceToHost, st));
+        OEI_HIP_CHECK(hipMemcpyAsync(count_host, oei_lbfgs_count_ptr(B, n, history, dws, iws), sizeof(int), hipMemcpyDeviceToHost, st));
         OEI_HIP_CHECK(hipStreamSynchronize(st));
     }
     return OEI_OK;

@@ -25,7 +25,7 @@ constexpr int LADDER = 12;
 struct NewtonView {
     int B, n;
     double *x, *f, *g, *d, *t, *xt, *Xc, *Xh, *lo, *hi;
-    int *status, *nit, *nfev, *nhev, *ls, *phase, *rowof, *map_t, *map_h, *counts, *need;
+    int *status, *nit, *nfev, *nhev, *ls, *phase, *rowof, *map_t, *map_h, *counts, *need, *rung;
 };
 
 inline size_t up32(size_t v) { return (v + 31) / 32 * 32; }
@@ -53,7 +53,7 @@ NewtonView make_view(int B, int n, double* dws, int* iws) {
     v.status = iws + oi[OEI_NEWTON_I_STATUS]; v.nit = iws + oi[OEI_NEWTON_I_NIT]; v.nfev = iws + oi[OEI_NEWTON_I_NFEV];
     v.nhev = iws + oi[OEI_NEWTON_I_NHEV]; v.ls = iws + oi[OEI_NEWTON_I_LS]; v.phase = iws + oi[OEI_NEWTON_I_PHASE];
     v.rowof = iws + oi[OEI_NEWTON_I_ROWOF]; v.map_t = iws + oi[OEI_NEWTON_I_MAP_T]; v.map_h = iws + oi[OEI_NEWTON_I_MAP_H];
-    v.counts = iws + oi[OEI_NEWTON_I_COUNTS]; v.need = iws + oi[OEI_NEWTON_I_NEED];
+    v.counts = iws + oi[OEI_NEWTON_I_COUNTS]; v.need = iws + oi[OEI_NEWTON_I_NEED]; v.rung = iws + oi[OEI_NEWTON_I_RUNG];
     return v;
 }
 
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64) void k_newton_init(NewtonView V, const double* 
     }
     if (lane == 0) {
         V.status[r] = ST_RUNNING; V.nit[r] = 0; V.nfev[r] = 0; V.nhev[r] = 0; V.ls[r] = 0; V.phase[r] = PH_TRIAL;
-        V.rowof[r] = r; V.map_t[r] = r; V.need[r] = 1;
+        V.rowof[r] = r; V.map_t[r] = r; V.need[r] = 1; V.rung[r] = 0;
         V.t[r] = 1.0; V.f[r] = INFINITY;
         if (r == 0) { V.counts[0] = V.B; V.counts[1] = 0; }
     }
@@ -107,9 +107,12 @@ __device__ __forceinline__ double masked_h(const double* __restrict__ H, int n, 
     return v;
 }
 
+// tstatus / tflags / flagged: as in k_lbfgs_step, for the rows of the trial list.
 __global__ __launch_bounds__(NT) void k_newton_step(NewtonView V, const double* __restrict__ ft,
                                                     const double* __restrict__ gt, const double* __restrict__ Ht,
-                                                    double pgtol, double ftol, double c1, int max_ls, int max_iter) {
+                                                    double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                                                    const int* __restrict__ tstatus, const int* __restrict__ tflags,
+                                                    int* __restrict__ flagged) {
     extern __shared__ double lds[];
     const int r = blockIdx.x, tid = threadIdx.x, n = V.n;
     const int LD = n | 1;
@@ -118,18 +121,23 @@ __global__ __launch_bounds__(NT) void k_newton_step(NewtonView V, const double* 
     double* bv = fm + n;                      // n: right-hand side, then the forward solution's workspace
     double* zv = bv + n;                      // n: solution
     double* red = zv + n;                     // 4
-    if (tid == 0) V.need[r] = 0;
-    if (V.status[r] != ST_RUNNING) return;
+    if (V.status[r] != ST_RUNNING) { if (tid == 0) V.need[r] = 0; return; }
     const size_t o = (size_t)r * n;
     double* x = V.x + o; double* g = V.g + o; double* d = V.d + o; double* xt = V.xt + o;
     const double* lo = V.lo; const double* hi = V.hi;
     const int c = V.rowof[r];
+    if (V.phase[r] == PH_TRIAL && tflags && tflags[c]) {       // left as it is: the caller evaluates this point another way
+        if (tid == 0) { V.need[r] = 1; atomicAdd(flagged, 1); }
+        return;
+    }
+    __syncthreads();                       // every thread has read need / phase before they change
+    if (tid == 0) V.need[r] = 0;
     double fcur = V.f[r];
     double t = V.t[r];
     int nit = V.nit[r];
     if (V.phase[r] == PH_TRIAL) {
         // a run that waits for a trial value while the caller passed no list sees a rejected point
-        const double fv = (ft && gt) ? ft[c] : INFINITY;
+        const double fv = (ft && gt && !(tstatus && tstatus[c] != 0)) ? ft[c] : INFINITY;
         const double* gn = (ft && gt) ? gt + (size_t)c * n : g;
         const int nfev = V.nfev[r] + 1;
         __syncthreads();
@@ -180,10 +188,16 @@ __global__ __launch_bounds__(NT) void k_newton_step(NewtonView V, const double* 
     double amax = 0.0;
     for (int e = tid; e < n * n; e += NT) amax = fmax(amax, fabs(masked_h(H, n, e / n, e % n, fm, 0.0)));
     const double scale = fmax(block_max(amax, red), 1e-12);
+    // rung k of the ladder: lam = 0 for k = 0, 1e-4 scale 10^(k-1) above; the climb starts two rungs
+    // below the rung this run's previous iteration ended on
+    const int first_rung = max(0, V.rung[r] - 2);
     double lam = 0.0;
+    for (int k = 1; k <= first_rung; ++k) lam = (k == 1) ? 1e-4 * scale : 10.0 * lam;
     bool solved = false;
+    int attempt = first_rung;
     const int ty = tid >> 4, tx = tid & 15;
-    for (int attempt = 0; attempt < LADDER && !solved; ++attempt) {
+    __syncthreads();                         // every thread has read the rung before thread 0 stores the new one
+    for (; attempt < LADDER && !solved; ++attempt) {
         // lower triangle of the masked matrix + lam I into LDS, then a right-looking factorisation
         // in place: pivot, scaled column, rank-one update of the trailing triangle spread over the
         // 16 x 16 thread grid (three barriers per column, no long dependent chains)
@@ -209,6 +223,7 @@ __global__ __launch_bounds__(NT) void k_newton_step(NewtonView V, const double* 
         if (!fail) { solved = true; break; }
         lam = (lam > 0.0) ? 10.0 * lam : 1e-4 * scale;
     }
+    if (tid == 0) V.rung[r] = solved ? attempt : 0;
     double gd = 0.0;
     if (solved) {
         for (int i = tid; i < n; i += NT) bv[i] = g[i] * fm[i];
@@ -322,6 +337,28 @@ extern "C" int oei_newton_init(int B, int n, const double* X0, const double* low
     return OEI_OK;
 }
 
+// The launches of one advance; tstatus / tflags / flagged as in k_newton_step (all optional).
+int oei_newton_advance_launch(int B, int n, const double* ft, const double* gt, const double* Ht,
+                              const int* tstatus, const int* tflags, int* flagged,
+                              double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                              double* dws, int* iws, hipStream_t st) {
+    NewtonView V = make_view(B, n, dws, iws);
+    const size_t lds = step_lds_bytes(n);
+    if (lds > 48 * 1024)
+        OEI_HIP_CHECK(hipFuncSetAttribute((const void*)k_newton_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_newton_step, dim3(B), dim3(NT), lds, st, V, ft, gt, Ht, pgtol, ftol, c1, max_ls, max_iter,
+                       tstatus, tflags, flagged);
+    hipLaunchKernelGGL(k_newton_compact, dim3(1), dim3(1024), 0, st, V);
+    hipLaunchKernelGGL(k_newton_gather, dim3(B), dim3(64), 0, st, V);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
+}
+
+int* oei_newton_counts_ptr(int B, int n, double* dws, int* iws) { return make_view(B, n, dws, iws).counts; }
+double* oei_newton_trial_list_ptr(int B, int n, double* dws, int* iws) { return make_view(B, n, dws, iws).Xc; }
+double* oei_newton_hess_list_ptr(int B, int n, double* dws, int* iws) { return make_view(B, n, dws, iws).Xh; }
+int oei_newton_check_shape(const char* who, int B, int n) { return check_shape(who, B, n); }
+
 extern "C" int oei_newton_advance(int B, int n, const double* ft, const double* gt, const double* Ht,
                                   double pgtol, double ftol, double c1, int max_ls, int max_iter,
                                   double* dws, int* iws, int* counts_host, void* stream) {
@@ -330,16 +367,11 @@ extern "C" int oei_newton_advance(int B, int n, const double* ft, const double* 
     if (!dws || !iws) { oei_set_error("newton_advance: null workspace"); return OEI_ERR_ARG; }
     if (max_ls < 1 || max_iter < 0) { oei_set_error("newton_advance: max_ls >= 1 and max_iter >= 0 required"); return OEI_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    NewtonView V = make_view(B, n, dws, iws);
-    const size_t lds = step_lds_bytes(n);
-    if (lds > 48 * 1024)
-        OEI_HIP_CHECK(hipFuncSetAttribute((const void*)k_newton_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_newton_step, dim3(B), dim3(NT), lds, st, V, ft, gt, Ht, pgtol, ftol, c1, max_ls, max_iter);
-    hipLaunchKernelGGL(k_newton_compact, dim3(1), dim3(1024), 0, st, V);
-    hipLaunchKernelGGL(k_newton_gather, dim3(B), dim3(64), 0, st, V);
-    OEI_HIP_CHECK(hipGetLastError());
+    const int lrc = oei_newton_advance_launch(B, n, ft, gt, Ht, nullptr, nullptr, nullptr, pgtol, ftol, c1, max_ls,
+                                              max_iter, dws, iws, st);
+    if (lrc) return lrc;
     if (counts_host) {
-        OEI_HIP_CHECK(hipMemcpyAsync(counts_host, V.counts, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        OEI_HIP_CHECK(hipMemcpyAsync(counts_host, oei_newton_counts_ptr(B, n, dws, iws), 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         OEI_HIP_CHECK(hipStreamSynchronize(st));
     }
     return OEI_OK;

@@ -214,6 +214,7 @@ def minimize_lockstep_newton(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-
     done = bad0.clone()
     converged = torch.zeros(B, dtype=torch.bool, device=dev)
     eye = torch.eye(n, dtype=dt, device=dev)
+    rung = torch.zeros(B, dtype=torch.int64, device=dev)
     for _ in range(max_iter):
         pg = x - torch.minimum(torch.maximum(x - g, lo), hi)
         hit = (pg.abs().amax(dim=1) <= pgtol) & ~done
@@ -230,17 +231,25 @@ def minimize_lockstep_newton(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-
         fm = free.to(dt)
         Hm = H * fm[:, :, None] * fm[:, None, :] + torch.diag_embed(1.0 - fm)
         scale = torch.clamp(Hm.abs().amax(dim=(1, 2)), min=1e-12)
-        lam = torch.zeros(idx.numel(), dtype=dt, device=dev)
-        L = None
-        for k in range(12):
-            Lk, info = torch.linalg.cholesky_ex(Hm + lam[:, None, None] * eye)
-            ok = info == 0
-            L = Lk if L is None else torch.where(ok[:, None, None] & (solved == 0)[:, None, None], Lk, L)
-            solved = ok.to(torch.int32) if k == 0 else torch.maximum(solved, ok.to(torch.int32))
-            if bool((solved == 1).all()):
+        # rung k of the ladder: lam = 0 (k = 0), 1e-4 scale 10^(k-1) above; a run starts its climb two
+        # rungs below the rung its previous iteration ended on
+        k_run = torch.clamp(rung[idx] - 2, min=0)
+        lam = torch.where(k_run > 0, 1e-4 * scale * 10.0 ** (k_run - 1).to(dt), torch.zeros_like(scale))
+        L = eye.expand(idx.numel(), n, n).clone()
+        solved = torch.zeros(idx.numel(), dtype=torch.int32, device=dev)
+        for _k in range(12):
+            trying = (solved == 0) & (k_run < 12)
+            if not bool(trying.any()):
                 break
-            lam = torch.where(solved == 1, lam, torch.where(lam > 0, 10.0 * lam, 1e-4 * scale))
+            Lk, info = torch.linalg.cholesky_ex(Hm + lam[:, None, None] * eye)
+            ok = (info == 0) & trying
+            L = torch.where(ok[:, None, None], Lk, L)
+            solved = torch.maximum(solved, ok.to(torch.int32))
+            climb = trying & ~ok
+            lam = torch.where(climb, torch.where(lam > 0, 10.0 * lam, 1e-4 * scale), lam)
+            k_run = torch.where(climb, k_run + 1, k_run)
         unsolved = solved == 0
+        rung[idx] = torch.where(unsolved, torch.zeros_like(k_run), k_run)
         d = -torch.cholesky_solve((ga * fm)[:, :, None], torch.where(unsolved[:, None, None], eye.expand_as(L), L))[:, :, 0] * fm
         gd = (ga * d).sum(dim=1)
         resetv = ~(gd < 0) | unsolved
@@ -276,7 +285,7 @@ def minimize_lockstep_newton(fun, hess, X0, lower, upper, max_iter=60, pgtol=1e-
 
 
 NEWTON_D = dict(X=0, F=1, G=2, DIR=3, STEP=4, XT=5, XC=6, XH=7, LO=8, HI=9)
-NEWTON_I = dict(STATUS=0, NIT=1, NFEV=2, NHEV=3, LS=4, PHASE=5, ROWOF=6, MAP_T=7, MAP_H=8, COUNTS=9, NEED=10)
+NEWTON_I = dict(STATUS=0, NIT=1, NFEV=2, NHEV=3, LS=4, PHASE=5, ROWOF=6, MAP_T=7, MAP_H=8, COUNTS=9, NEED=10, RUNG=11)
 NEWTON_MAX_N = 141
 
 
@@ -330,6 +339,107 @@ def minimize_lockstep_newton_device(fun, hess, X0, lower, upper, max_iter=60, pg
                                          p(dws), p(iws), cnt, stream), 'oei_newton_advance')
             n_trial, n_hess = cnt[0], cnt[1]
             if n_trial == 0 and n_hess == 0:
+                break
+    status = iview('STATUS').clone()
+    converged = (status == 1) | (status == 2)
+    message = [LBFGS_STATUS[s] for s in status.tolist()]
+    return LockstepResult(x=dview('X', B, n).clone(), fun=dview('F', B).clone(), grad=dview('G', B, n).clone(),
+                          nit=iview('NIT').to(torch.int64), nfev=iview('NFEV').to(torch.int64),
+                          converged=converged, message=message)
+
+
+def minimize_acquisition_rounds(gp, q, X0, lower, upper, method='lbfgs', project_fallback=None, history=10,
+                                max_iter=None, pgtol=1e-5, ftol=2.2e-9, c1=1e-4, max_ls=None):
+    """The multistart descent on the acquisition of `gp` with the loop over rounds inside the
+    library (`oei_lbfgs_minimize_rounds` / `oei_newton_minimize_rounds`): same state machines, same
+    constants and results as `minimize_lockstep_device` / `minimize_lockstep_newton_device` driven
+    with `acquisition_fun` / `acquisition_hess_fun`, without the per-round host work of a Python loop
+    (at the 20 starts of a BO loop a round is then bound by the device, not by the host).
+    A trial point that the reference's `project` would shrink (only with `project_fallback`, and
+    noise <= 1e-4) hands one round back to Python: the list is evaluated through `acquisition_fun`
+    with the fallback, the runs advance once, and the library loop goes on.
+    Iteration caps: L-BFGS 2000 (scipy's L-BFGS-B default is 15000, solvers.py:11-17: the stopping
+    rules pgtol / ftol end the runs, the cap is a safety net), Newton 200."""
+    import ctypes
+    from ._lib import lib, check
+    newton = method == 'newton'
+    if max_iter is None:
+        max_iter = 200 if newton else 2000
+    if max_ls is None:
+        max_ls = 20 if newton else 25
+    x0 = torch.as_tensor(X0, dtype=torch.float64, device=gp.device).contiguous()
+    B, n = x0.shape
+    d = gp.dim
+    assert n == q * d
+    dev = gp.device
+    lo = torch.as_tensor(lower, dtype=torch.float64, device=dev).expand(n).contiguous()
+    hi = torch.as_tensor(upper, dtype=torch.float64, device=dev).expand(n).contiguous()
+    nd, ni, nw = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    names_d, names_i = (NEWTON_D, NEWTON_I) if newton else (LBFGS_D, LBFGS_I)
+    od = (ctypes.c_size_t * len(names_d))()
+    oi = (ctypes.c_size_t * len(names_i))()
+    if newton:
+        check(lib.oei_newton_layout(B, n, ctypes.byref(nd), ctypes.byref(ni), od, oi), 'oei_newton_layout')
+    else:
+        check(lib.oei_lbfgs_layout(B, n, history, ctypes.byref(nd), ctypes.byref(ni), od, oi), 'oei_lbfgs_layout')
+    check(lib.oei_multistart_workspace(B, n, int(newton), ctypes.byref(nw)), 'oei_multistart_workspace')
+    dws = torch.zeros(nd.value, dtype=torch.float64, device=dev)
+    iws = torch.zeros(ni.value, dtype=torch.int32, device=dev)
+    work = torch.empty(nw.value, dtype=torch.float64, device=dev)
+
+    def dview(name, *shape):
+        o = od[names_d[name]]
+        return dws[o:o + int(torch.Size(shape).numel())].view(*shape)
+
+    def iview(name, count=B):
+        o = oi[names_i[name]]
+        return iws[o:o + count]
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    projecting = project_fallback is not None and gp.noise <= 1e-4
+    use_flags = (1 if projecting else 0) | (2 if gp.noise <= 1e-4 else 0)
+    fun = hess = None
+    info = (ctypes.c_int * 4)()
+    with torch.cuda.device(dev):
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if newton:
+            check(lib.oei_newton_init(B, n, p(x0), p(lo), p(hi), p(dws), p(iws), stream), 'oei_newton_init')
+        else:
+            check(lib.oei_lbfgs_init(B, n, history, p(x0), p(lo), p(hi), p(dws), p(iws), stream), 'oei_lbfgs_init')
+        info[0], info[1] = B, 0
+        while True:
+            if newton:
+                check(lib.oei_newton_minimize_rounds(gp._h, B, q, pgtol, ftol, c1, max_ls, max_iter, p(dws), p(iws),
+                                                     p(work), use_flags, 1 << 30, info, stream), 'oei_newton_minimize_rounds')
+                n_trial, n_hess, flagged = info[0], info[1], info[2]
+            else:
+                check(lib.oei_lbfgs_minimize_rounds(gp._h, B, q, history, pgtol, ftol, c1, max_ls, max_iter, p(dws),
+                                                    p(iws), p(work), use_flags, 1 << 30, info, stream), 'oei_lbfgs_minimize_rounds')
+                n_trial, n_hess, flagged = info[0], 0, info[1]
+            if n_trial == 0 and n_hess == 0:
+                break
+            assert flagged > 0, 'the round loop returned with runs left and nothing to hand back'
+            # one round through the host: the flagged trial points get the reduced problem's value
+            if fun is None:
+                fun = acquisition_fun(gp, q, project_fallback)
+                hess = acquisition_hess_fun(gp, q)
+            ft = gt = Ht = None
+            if n_trial > 0:
+                ft, gt = fun(dview('XC', B, n)[:n_trial])
+                ft = ft.to(torch.float64).contiguous()
+                gt = gt.to(torch.float64).reshape(n_trial, n).contiguous()
+            if newton:
+                if n_hess > 0:
+                    Ht = hess(dview('XH', B, n)[:n_hess]).to(torch.float64).reshape(n_hess, n, n).contiguous()
+                cnt = (ctypes.c_int * 2)()
+                check(lib.oei_newton_advance(B, n, p(ft), p(gt), p(Ht), pgtol, ftol, c1, max_ls, max_iter,
+                                             p(dws), p(iws), cnt, stream), 'oei_newton_advance')
+                info[0], info[1] = cnt[0], cnt[1]
+            else:
+                cnt = ctypes.c_int(0)
+                check(lib.oei_lbfgs_advance(B, n, history, p(ft), p(gt), pgtol, ftol, c1, max_ls, max_iter,
+                                            p(dws), p(iws), ctypes.byref(cnt), stream), 'oei_lbfgs_advance')
+                info[0] = cnt.value
+            if info[0] == 0 and (not newton or info[1] == 0):
                 break
     status = iview('STATUS').clone()
     converged = (status == 1) | (status == 2)
@@ -412,23 +522,35 @@ def optimize_multistart(gp, X_starts, lower, upper, index_base=0, group=None, pr
     hi = torch.as_tensor(upper, dtype=torch.float64, device=gp.device)
     if lo.numel() == d:
         lo, hi = lo.repeat(q), hi.repeat(q)
+    plain = not warm_start and stats is None
     if method == 'newton':
         # exact second-order steps on the batched Hessian, then the first-order method polishes
         # the runs the Newton iteration left unconverged (it stops at the first rejected step)
         fun = acquisition_fun(gp, q, project_fallback, stats=stats)
-        newton = minimize_lockstep_newton_device if q * d <= NEWTON_MAX_N else minimize_lockstep_newton
-        res = newton(fun, acquisition_hess_fun(gp, q), X0, lo, hi,
-                     **{k: v for k, v in kwargs.items() if k in ('max_iter', 'pgtol', 'ftol')})
+        nk = {k: v for k, v in kwargs.items() if k in ('max_iter', 'pgtol', 'ftol')}
+        if plain and q * d <= NEWTON_MAX_N:
+            res = minimize_acquisition_rounds(gp, q, X0, lo, hi, method='newton', project_fallback=project_fallback, **nk)
+        else:
+            newton = minimize_lockstep_newton_device if q * d <= NEWTON_MAX_N else minimize_lockstep_newton
+            res = newton(fun, acquisition_hess_fun(gp, q), X0, lo, hi, **nk)
         todo = torch.nonzero(~res.converged & torch.isfinite(res.fun)).reshape(-1)
         if todo.numel() > 0:
-            r2 = minimize_lockstep_device(fun, res.x[todo], lo, hi, **kwargs)
+            pk = {k: v for k, v in kwargs.items() if k != 'max_iter'}
+            if plain:
+                r2 = minimize_acquisition_rounds(gp, q, res.x[todo], lo, hi, project_fallback=project_fallback, **pk)
+            else:
+                r2 = minimize_lockstep_device(fun, res.x[todo], lo, hi, **pk)
             res.x[todo], res.fun[todo], res.grad[todo] = r2.x, r2.fun, r2.grad
             res.nit[todo] += r2.nit
             res.nfev[todo] += r2.nfev
             res.converged[todo] = r2.converged
+    elif plain:
+        res = minimize_acquisition_rounds(gp, q, X0, lo, hi, project_fallback=project_fallback, **kwargs)
     else:
+        kw = dict(kwargs)
+        kw.setdefault('max_iter', 2000)
         res = minimize_lockstep_device(acquisition_fun(gp, q, project_fallback, n_runs=B, warm_start=warm_start, stats=stats),
-                                       X0, lo, hi, **kwargs)
+                                       X0, lo, hi, **kw)
     fv = torch.where(torch.isfinite(res.fun), res.fun, torch.full_like(res.fun, float('nan')))
     bv, bi = engine.argmin(fv, index_base)
     local = torch.clamp(bi - index_base, min=0)

@@ -122,7 +122,7 @@ class BO(object):
 
     def get_suggestion(self, batch_size):
         """bo.py:129-192: multistart descent on the acquisition function."""
-        if self.options['nl_solver'] == 'lockstep':
+        if self.options['nl_solver'] in ('lockstep', 'lockstep-newton'):
             return self._get_suggestion_lockstep(batch_size)
         X, y = None, None
         bounds_tiled = np.tile(self.bounds, (batch_size, 1))
@@ -148,16 +148,23 @@ class BO(object):
         from .. import lockstep
         starts = np.stack([self.random_sample(self.bounds, batch_size)
                            for _ in range(self.options['opt_restarts'])])
-        # options['hessian'] (run.py --hessian, the flag that makes the reference hand exact
-        # Hessians to its SQP solver, solvers.py:56-69) selects the projected Newton iteration
+        # 'lockstep' is the batched counterpart of the reference's 'bfgs' (which ignores the
+        # `hessian` option, solvers.py:10-17); 'lockstep-newton' that of its SQP solver, which is
+        # handed exact Hessians when options['hessian'] is set (run.py --hessian, solvers.py:56-69)
+        newton = self.options['nl_solver'] == 'lockstep-newton' and bool(self.options.get('hessian', 1))
         res, best = lockstep.optimize_multistart(
             self.device_model(), starts, self.bounds[:, 0], self.bounds[:, 1],
             project_fallback=lambda x: (lambda r: (r[0][0], r[1]))(self.acquisition(x)),
-            method='newton' if self.options.get('hessian') else 'lbfgs')
+            method='newton' if newton else 'lbfgs')
         log = logging.getLogger('opt')
         fun, nit = res.fun.cpu().numpy(), res.nit.cpu().numpy()
         for j in range(len(fun)):
             log.info('##Opt_it:' + str(j + 1) + ' Val:' + '%.2e' % fun[j] + ' It:' + str(int(nit[j])))
+        # how the runs ended (scipy reports this per start as status.message, bo.py:176-177)
+        stopped = len(fun) - int(res.converged.sum().item())
+        log.info('##Opt_runs:' + str(len(fun)) + ' converged:' + str(len(fun) - stopped) + ' stopped at a limit:' + str(stopped))
+        if stopped:
+            log.warning('NLP Warning: %d of %d runs stopped at the iteration or line-search limit' % (stopped, len(fun)))
         assert int(best[1].item()) >= 0
         return best[2].cpu().numpy()
 

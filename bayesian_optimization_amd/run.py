@@ -5,8 +5,10 @@
 
 writes `out/<function>_<algorithm>/<seed>.npz` (arrays X, Y), `arguments.pkl`, `fmin.txt`
 (run.py:26-71, 105-133) and logs to `log/<job>/<seed>/` (bo.py:257-276).  Differences, all forced by what
-is installed: `--nl_solver` defaults to `lockstep` (the reference's default, KNITRO, is proprietary;
-`bfgs` and `newton` are the other choices), the objective comes from `oracle/hart6.py`-equivalent
+is installed: `--nl_solver` defaults to `lockstep` (the reference's default, KNITRO, is proprietary):
+all `opt_restarts` bounded L-BFGS runs of a BO iteration advanced together on the GPU, the batched
+counterpart of `bfgs`; `lockstep-newton` is the batched consumer of the exact Hessian (`--hessian 1`),
+which KNITRO is in the reference; `bfgs` and `newton` run one start after the other, the objective comes from `oracle/hart6.py`-equivalent
 formulas in `benchmarks.py`, the kernels are this package's descriptions instead of gpflow objects,
 and the GP hyper-parameters are fitted by `hyperfit.py` on the GPU.
 """

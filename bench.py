@@ -349,9 +349,13 @@ def main():
                 res, _ = lockstep.optimize_multistart(gp, Xs, [-0.5] * d, [0.5] * d)
                 torch.cuda.synchronize()
                 tm = time.perf_counter() - tm
+                import collections
                 callers = {'multistart': {'starts': nstart, 'seconds': tm, 'evaluations': int(res.nfev.sum().item()),
                                           'converged': int(res.converged.sum().item()),
-                                          'method': 'bounded L-BFGS, state on the device (oei_lbfgs_advance)'}}
+                                          'rounds': int(res.nfev.max().item()),
+                                          'stop_reasons': dict(collections.Counter(res.message)),
+                                          'method': 'bounded L-BFGS, state on the device, rounds driven inside the library '
+                                                    '(oei_lbfgs_minimize_rounds), iteration cap 2000'}}
                 hyperfit.fit(gp.X_train, gp.y_train, gp.kernel_kind, 1.0, 1.0, gp.noise, floor_mode=gp.floor_mode,
                              restarts=2, rng=np.random.RandomState(0))
                 tf = time.perf_counter()

@@ -303,12 +303,14 @@ int oei_lbfgs_advance(int B, int n, int history, const double* ft, const double*
  * reference's SQP solver with `--hessian 1`, solvers.py:56-69, 71-141): a running run waits either
  * for value and gradient at its trial point (list XC, COUNTS[0] rows) or for the Hessian at its
  * iterate (list XH, COUNTS[1] rows).  Direction: (H + lam I) d = -g on the variables not blocked at
- * a bound, lam from the ladder 0, 1e-4 s, 1e-3 s, ... (s = max |H_ij|, 12 steps) until the matrix is
- * positive definite, else steepest descent; projected backtracking (step / 4), stopping rules as
+ * a bound, lam from the ladder 0, 1e-4 s, 1e-3 s, ... (s = max |H_ij|, 12 rungs) until the matrix is
+ * positive definite, else steepest descent; the climb starts two rungs below the rung the run's
+ * previous iteration ended on (RUNG), so that a run far from an optimum does not repeat the failed
+ * factorisations of the low rungs every iteration; projected backtracking (step / 4), stopping rules as
  * above.  The factor lives in LDS: n <= OEI_NEWTON_MAX_N variables per run.
  *   doubles  X | F | G | DIR | STEP | XT | XC [B,n] trial list | XH [B,n] Hessian list | LO | HI
  *   ints     STATUS (OEI_LBFGS_* codes) | NIT | NFEV | NHEV Hessian evaluations | LS | PHASE |
- *            ROWOF row of run r in its list | MAP_T, MAP_H run of a list row | COUNTS [2] | NEED */
+ *            ROWOF row of run r in its list | MAP_T, MAP_H run of a list row | COUNTS [2] | NEED | RUNG */
 #define OEI_NEWTON_MAX_N 141
 #define OEI_NEWTON_D_X 0
 #define OEI_NEWTON_D_F 1
@@ -332,7 +334,8 @@ int oei_lbfgs_advance(int B, int n, int history, const double* ft, const double*
 #define OEI_NEWTON_I_MAP_H 8
 #define OEI_NEWTON_I_COUNTS 9
 #define OEI_NEWTON_I_NEED 10
-#define OEI_NEWTON_NI 11
+#define OEI_NEWTON_I_RUNG 11
+#define OEI_NEWTON_NI 12
 int oei_newton_layout(int B, int n, size_t* n_doubles, size_t* n_ints,
                       size_t* off_doubles, size_t* off_ints);
 int oei_newton_init(int B, int n, const double* X0, const double* lower, const double* upper,
@@ -345,6 +348,32 @@ int oei_newton_init(int B, int n, const double* X0, const double* lower, const d
 int oei_newton_advance(int B, int n, const double* ft, const double* gt, const double* Ht,
                        double pgtol, double ftol, double c1, int max_ls, int max_iter,
                        double* dws, int* iws, int* counts_host, void* stream);
+
+/* ---- rounds of the multistart driven inside the library -------------------------------------------
+ * The loop over rounds of bo.py:129-192's multistart for the acquisition of model m: per round
+ * the library evaluates the dense list(s) of the running runs itself (oei_value_grad_batched,
+ * oei_hessian_batched with the Hessian zeroed where `project` would shrink the candidate,
+ * oei.py:53-55), advances every run (a solve that failed is a rejected trial point) and reads the
+ * list length(s) back; the caller's Python loop pays per round what the device work costs at 20
+ * starts.  State: the workspaces of oei_lbfgs_init / oei_newton_init (n = q d variables per run).
+ * work: device scratch of oei_multistart_workspace(B, n, with_hessian) doubles.
+ * use_flags bit 0 (for noise <= 1e-4, oei.py:174): a trial point that `project` would shrink stops
+ * the loop before its run is advanced -- the run and its trial point stay in the list; bit 1: the
+ * Hessian of such a candidate is zeroed.  The caller
+ * then evaluates the current list itself (the reduced problem draws random directions on the
+ * host, oei.py:186-187), advances once with oei_lbfgs_advance / oei_newton_advance and calls again.
+ * info (host): L-BFGS in [count] out [count, flagged runs, rounds done]; Newton in [trial count,
+ * Hessian count] out [trial count, Hessian count, flagged runs, rounds done].  Returns after
+ * max_rounds rounds, when no run is left, or at a flagged trial point.  Synchronous. */
+int oei_multistart_workspace(int B, int n, int with_hessian, size_t* n_doubles);
+int oei_lbfgs_minimize_rounds(oei_model* m, int B, int q, int history,
+                              double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                              double* dws, int* iws, double* work, int use_flags,
+                              int max_rounds, int* info, void* stream);
+int oei_newton_minimize_rounds(oei_model* m, int B, int q,
+                               double pgtol, double ftol, double c1, int max_ls, int max_iter,
+                               double* dws, int* iws, double* work, int use_flags,
+                               int max_rounds, int* info, void* stream);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,18 @@ def test_cfg5_driver_with_reference_flags(cuda, tmp_path, monkeypatch):
         assert len([l for l in fh if l.startswith('X:')]) == 310
     run.main(args)
     assert np.array_equal(np.load(os.path.join('out', 'hart6_OEI', '123.npz'))['X'], X)
+    # the multistart runs end on a stopping rule (projected gradient, relative decrease), not on a cap
+    with open(os.path.join('log', 'hart6_OEI', '123', 'opt.log')) as fh:
+        runs = [l for l in fh if l.startswith('##Opt_runs:')]
+    conv = [int(l.split('converged:')[1].split()[0]) for l in runs]
+    assert len(runs) == 15 and min(conv) >= 16 and sum(conv) >= 0.9 * 300, conv       # at least 90 % overall
+    # the same loop with the exact Hessian consumed by the batched Newton iteration (the role of the
+    # reference's default solver): also 310 evaluations and a best value near the minimum
+    args_n = run.create_parser().parse_args(['--seed=123', '--function=hart6', '--batch_size=20', '--initial_size=10',
+                                             '--iterations=15', '--noise=1e-6', '--nl_solver=lockstep-newton'])
+    run.main(args_n)
+    Yn = np.load(os.path.join('out', 'hart6_OEI', '123.npz'))['Y']
+    assert Yn.shape == (310, 1) and Yn.min() <= -3.2, Yn.min()
 
 
 def test_cfg4_launcher_two_ranks_one_gpu(cuda):

@@ -183,3 +183,46 @@ def test_newton_device_useless_hessian_and_limits(cuda):
     assert res.message[2] == 'no finite start value' and bool(res.converged[[0, 1, 3, 4, 5]].all())
     with pytest.raises(_lib.OeiError):
         minimize_lockstep_newton_device(_rosen, _rosen_hess, torch.zeros(2, 142, dtype=torch.float64, device=cuda), -2.0, 0.8)
+
+
+def test_round_loop_inside_the_library_matches_the_python_loop(cuda):
+    """`minimize_acquisition_rounds` (rounds driven by oei_lbfgs_minimize_rounds /
+    oei_newton_minimize_rounds) against the same state machines driven round by round from Python
+    with `acquisition_fun` / `acquisition_hess_fun`: same evaluations, same advance kernels, so the
+    same iterates bit for bit, for both methods; and with a start on a training point the flagged
+    trial points go through the host and the runs still end finite and converged or stopped."""
+    from oracle import hart6, gp as ogp
+    from bayesian_optimization_amd import DeviceGP, lockstep
+    q, d = 5, 6
+    model = hart6.make_model(40)
+    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    X0 = torch.as_tensor(np.random.RandomState(11).uniform(-.5, .5, (24, q * d)), device=cuda)
+    lo = torch.full((q * d,), -0.5, dtype=torch.float64, device=cuda)
+    hi = -lo
+    fun = lockstep.acquisition_fun(gp, q)
+    ref = lockstep.minimize_lockstep_device(fun, X0, lo, hi, max_iter=300)
+    got = lockstep.minimize_acquisition_rounds(gp, q, X0, lo, hi, max_iter=300)
+    for a, b in zip((got.x, got.fun, got.grad, got.nit, got.nfev, got.converged),
+                    (ref.x, ref.fun, ref.grad, ref.nit, ref.nfev, ref.converged)):
+        assert torch.equal(a, b)
+    assert got.message == ref.message and int(got.converged.sum()) >= 20
+    refn = lockstep.minimize_lockstep_newton_device(fun, lockstep.acquisition_hess_fun(gp, q), X0, lo, hi, max_iter=80)
+    gotn = lockstep.minimize_acquisition_rounds(gp, q, X0, lo, hi, method='newton', max_iter=80)
+    for a, b in zip((gotn.x, gotn.fun, gotn.nit, gotn.nfev), (refn.x, refn.fun, refn.nit, refn.nfev)):
+        assert torch.equal(a, b)
+    # a start that duplicates a training point: handed back to the host for its rounds
+    calls = []
+
+    def fallback(xrow):
+        calls.append(1)
+        v, g, st, _ = gp.value_grad(xrow.reshape(1, q, d), want_flags=False)
+        return float(v.item()) + 0.25, g.reshape(-1).cpu().numpy()       # a different value: visibly the host's
+    Xd = X0.clone()
+    Xd[3, :d] = torch.as_tensor(model.X[7] + 1e-4, device=cuda)
+    for method in ('lbfgs', 'newton'):
+        calls.clear()
+        r = lockstep.minimize_acquisition_rounds(gp, q, Xd, lo, hi, method=method, project_fallback=fallback, max_iter=60)
+        assert len(calls) >= 1 and bool(torch.isfinite(r.fun).all())
+        others = [i for i in range(24) if i != 3]
+        base = lockstep.minimize_acquisition_rounds(gp, q, Xd, lo, hi, method=method, max_iter=60)
+        assert torch.equal(r.x[others], base.x[others])                   # the other runs never notice
