@@ -120,7 +120,7 @@ def assemble(p, st, mu, S, fmin, w0=1.0):
     return value, M, Y, p
 
 
-def sensitivity(p, st, mu, S, fmin, domegas, w0=1.0):
+def sensitivity(p, st, mu, S, fmin, domegas, w0=1.0, return_dp=False):
     """dM for perturbations dOmega[:, :, j] through the reduced optimality conditions
     N S N = D/4 and diag(B) - 2 B p = 4 (mu - fmin):  with dN = U Z U^T,
     Z_ab = 2 (R^T (dD/4 - N dS N) R)_ab / (sq_a + sq_b), dB = -4 R (sq Z sq) R^T, and dp from the
@@ -135,6 +135,7 @@ def sensitivity(p, st, mu, S, fmin, domegas, w0=1.0):
     c = mu + 0.5 * B @ p
     Phi = 2.0 / (sq[:, None] + sq[None, :])
     dM = np.zeros((q + 1, q + 1, K))
+    dps = np.zeros((q, K))
     om11 = S + np.outer(mu, mu)
     for j in range(K):
         dO = 0.5 * (domegas[:, :, j] + domegas[:, :, j].T)
@@ -146,6 +147,7 @@ def sensitivity(p, st, mu, S, fmin, domegas, w0=1.0):
         dBS = -4.0 * (R * sq) @ ZS @ (R * sq).T
         rhs = dmu - 0.25 * (np.diag(dBS) - 2.0 * dBS @ p)
         dp = np.linalg.solve(H, rhs)
+        dps[:, j] = dp
         dD = np.diag(dp) - np.outer(dp, p) - np.outer(p, dp)
         Z = ZS + 0.25 * (R.T @ dD @ R) * Phi
         dN = U @ Z @ U.T
@@ -157,4 +159,4 @@ def sensitivity(p, st, mu, S, fmin, domegas, w0=1.0):
         dM[:q, q, j] = -dn
         dM[q, :q, j] = -dn
         dM[q, q, j] = -dnu
-    return dM
+    return (dM, dps) if return_dp else dM
