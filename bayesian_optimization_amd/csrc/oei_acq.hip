@@ -174,6 +174,9 @@ __device__ __forceinline__ void posterior_moments_mfma(const SdpWork w, const Ke
             }
         }
     }
+#ifdef OEI_SDP_TIMING
+    const long long tm_loop = clock64();
+#endif
     // accumulator g of lane l is entry (row (l >> 4) + 4 g, column l & 15) of its tile
     {
         int t = 0;
@@ -189,9 +192,9 @@ __device__ __forceinline__ void posterior_moments_mfma(const SdpWork w, const Ke
                 }
     }
     __syncthreads();
-    for (int e = lane; e < q * q; e += 64) {
-        const int i = e / q, j = e - i * q;
-        if (j > i) continue;
+    for (int e = lane; e < q * (q + 1) / 2; e += 64) {      // lower triangle only: a kernel evaluation per entry
+        int i, j;
+        sdp_tri_index(e, i, j);
         double t = 0.0;
         for (int l = 0; l < d; ++l) {
             const double df = xq[i * d + l] - xq[j * d + l];
@@ -204,6 +207,9 @@ __device__ __forceinline__ void posterior_moments_mfma(const SdpWork w, const Ke
         w.S[j * LD + i] = val;
     }
     __syncthreads();
+#ifdef OEI_SDP_TIMING
+    if (lane == 0) mu[q + 1] = (double)(clock64() - tm_loop);     // cycles after the row loop (diagnostic)
+#endif
 }
 
 // Z[a, k] = -sum_b N[a][b] A[b][k] for the one-wave kernels, on the matrix pipe: N (w.H) is the
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
         if (tid == 0 && q >= 12) {
             so[0] = (double)(tk1 - tk0); so[1] = (double)(tk2 - tk1); so[2] = (double)(tk3 - tk2); so[3] = (double)(tk4 - tk3);
             for (int i = 0; i < 8; ++i) so[4 + i] = w.scal[i];
+            so[12] = mu[q + 1];
         }
     }
 #endif

@@ -16,4 +16,5 @@ c = out[4].cpu().numpy()
 names = ['moments', 'solve', 'primal', 'outputs + Z', ' eval set-up', ' jacobi', ' eval rest', ' newton dir', '  hess items', '  cholesky']
 for nm, v in zip(names, c[:, :10].mean(axis=0)):
     print('%-14s %9.0f cycles' % (nm, v))
+print('moments: after the row loop (store, kernel entries) %9.0f cycles' % c[:, 12].mean())
 print('kernel total   %9.0f cycles per wave' % c[:, :4].sum(axis=1).mean())
