@@ -1,0 +1,40 @@
+#!/bin/bash
+# Turns what tools/collect_profiles_r03.sh left under gpurun_out/r03/ into the files kept in profiles/.
+set -e
+O=gpurun_out/r03
+python tools/kernel_stats_csv.py $O/stats/stats_kernel_stats.csv profiles/r03_kernel_stats.csv
+python tools/kernel_stats_csv.py $O/stats2/stats2_kernel_stats.csv profiles/r03_kernel_stats_two_streams.csv
+python tools/kernel_stats_csv.py $O/statsh/statsh_kernel_stats.csv profiles/r03_hessian_kernel_stats.csv
+python tools/kernel_stats_csv.py $O/cfg3/cfg3_kernel_stats.csv profiles/r03_cfg3_kernel_stats.csv
+python tools/kernel_stats_csv.py $O/hess3/hess3_kernel_stats.csv profiles/r03_hess_cfg3_kernel_stats.csv
+python tools/kernel_stats_csv.py $O/round_lbfgs/round_lbfgs_kernel_stats.csv profiles/r03_round_lbfgs_kernel_stats.csv
+python tools/kernel_stats_csv.py $O/round_newton/round_newton_kernel_stats.csv profiles/r03_round_newton_kernel_stats.csv
+python tools/pmc_summary_csv.py $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv profiles/r03_pmc_hbm.json > /dev/null
+cp $O/bench.json profiles/r03_bench.json
+cp $O/bench_single.json profiles/r03_bench_single_stream.json
+cp $O/bench_collective.json profiles/r03_bench_collective.json
+cp $O/cfg3_roofline.json profiles/r03_cfg3_roofline.json
+F='amdgpu.ids\|rocprofv3\|output_stream\|tool.cpp'
+grep -v "$F" $O/cfg3.log > profiles/r03_cfg3.log
+grep -v "$F" $O/hess3.log > profiles/r03_hess_cfg3.log
+grep -v "$F" $O/model.log > profiles/r03_model_create.log
+grep -v "$F" $O/hess_small.log > profiles/r03_hessian_small.log
+grep -v "$F" $O/lockstep.log > profiles/r03_lockstep.log
+grep -v "$F" $O/fit.log > profiles/r03_fit.log
+grep -v "$F" $O/phase_cycles.log > profiles/r03_phase_cycles.log
+if [ -f $O/micro_mixed_pipes.log ]; then cp $O/micro_mixed_pipes.log profiles/r03_micro_mixed_pipes.log; grep -v "$F" $O/warm_probe_first_order.log > profiles/r03_warm_probe_first_order.log; fi
+(grep -v "$F" $O/round_lbfgs.log; grep -v "$F" $O/round_newton.log) > profiles/r03_round.log
+(grep "^pass" $O/bo_loop_lbfgs.log | sed 's/^/--nl_solver=lockstep (default) --hessian=0: /'; grep "^pass" $O/bo_loop_newton.log | sed 's/^/--nl_solver=lockstep-newton: /') > profiles/r03_bo_loop.log
+python - <<'PY'
+import json
+h = json.load(open('profiles/r03_pmc_hbm.json'))
+p = 'profiles/pmc_traffic.json'
+d = json.load(open(p))
+step = {k: h[k]['hbm_bytes_per_launch'] for k in ('k_gram<true>', 'k_gemm_nt_tall', 'k_stage2<64, 20>', 'k_gemm_grad<8>', 'k_grad_fin', 'k_best_record')}
+d['moments_sdp_hbm_bytes_per_launch'] = step['k_stage2<64, 20>']
+d['step_hbm_bytes_by_kernel'] = step
+d['step_hbm_bytes'] = sum(step.values())
+d['source'] = 'profiles/r03_pmc_hbm.json'
+json.dump(d, open(p, 'w'), indent=1)
+print(step, d['step_hbm_bytes'])
+PY
