@@ -211,6 +211,21 @@ __device__ __forceinline__ double sdp_sum8(double v) {
     return v;
 }
 
+// Sum / maximum over lanes 0..31 of a wave, identical bits in every lane (butterfly inside the two
+// 16-lane rows, then the two row results through the scalar unit).  All 64 lanes must be active.
+__device__ __forceinline__ double sdp_sum32(double v) {
+    v = sdp_sum8(v);
+    v += sdp_dpp<0x140>(v);       // row_mirror
+    return sdp_lane_bcast(v, 0) + sdp_lane_bcast(v, 16);
+}
+__device__ __forceinline__ double sdp_max32(double v) {
+    v = fmax(v, sdp_dpp<0xB1>(v));
+    v = fmax(v, sdp_dpp<0x4E>(v));
+    v = fmax(v, sdp_dpp<0x141>(v));
+    v = fmax(v, sdp_dpp<0x140>(v));
+    return fmax(sdp_lane_bcast(v, 0), sdp_lane_bcast(v, 16));
+}
+
 // In-place Cholesky of the lower triangle of A (q x q, leading dimension LD) by T threads.
 // Returns 1 at the first non-positive pivot (identical in every thread).
 template <int T>
@@ -1575,11 +1590,20 @@ __device__ __forceinline__ int sdp_solve_impl(const SdpWork w, double* g_out, in
         if (dir_fail) { status = 2; break; }
         double ssum = 0.0, psum = 0.0;
         rel = 0.0; dec = 0.0;
-        for (int i = 0; i < q; ++i) {
-            const double st = w.step[i];
-            rel = fmax(rel, fabs(st) / w.p[i]);
-            ssum += st; psum += w.p[i];
-            dec += w.grad[i] * st;
+        if constexpr (T == 64) {                         // one entry per lane (q <= 32), wave reductions
+            const bool in = tid < q;
+            const double st = in ? w.step[tid] : 0.0, pi = in ? w.p[tid] : 1.0, gi = in ? w.grad[tid] : 0.0;
+            rel = sdp_max32(fabs(st) / pi);
+            ssum = sdp_sum32(st);
+            psum = sdp_sum32(in ? pi : 0.0);
+            dec = sdp_sum32(gi * st);
+        } else {
+            for (int i = 0; i < q; ++i) {
+                const double st = w.step[i];
+                rel = fmax(rel, fabs(st) / w.p[i]);
+                ssum += st; psum += w.p[i];
+                dec += w.grad[i] * st;
+            }
         }
         rel = fmax(rel, fabs(ssum) / (1.0 - psum));
         if (!(rel == rel)) { status = 2; break; }
