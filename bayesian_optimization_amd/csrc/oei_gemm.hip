@@ -156,149 +156,154 @@ int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int 
 // D[row = (l >> 4) + 4 g][col = l & 15].
 // Ag/Bg point at the first row of the two 64-row operand panels (leading dimension ld, K along
 // the row); Cg at the output tile (leading dimension ldc).
-__device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
-                                             const double* __restrict__ Bg0,
-                                             double* __restrict__ Cg, int ld, int ldc, int kbeg,
-                                             int kend, double* As, double* Bs, int tri) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    // staging map: thread t moves 4 consecutive doubles of row t/4
-    const int srow = tid >> 2;
-    const int scol = (tid & 3) * 4;
+// One K step (GM_BK columns) of a wave's share of the tile from the staged panels: NH groups of 16
+// rows against the 16-column groups TLO..THI.  `al` / `bl` point at the lane's entry of the first
+// row group / column group in the A / B panel.  All fragments of the step are read first, then
+// the matrix instructions run back to back (straight-line code: the group bounds are template
+// arguments, so that the skipped groups of a diagonal block cost no branch inside the step).
+template <int NH, int TLO, int THI>
+__device__ __forceinline__ void gemm_mma_step(const double* __restrict__ al, const double* __restrict__ bl,
+                                              double4_t (&acc)[NH][4]) {
+    double av[NH][GM_BK / 4], bv[4][GM_BK / 4];
+#pragma unroll
+    for (int ks = 0; ks < GM_BK / 4; ++ks) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) av[h][ks] = al[h * 16 * GM_LDS + ks * 4];
+#pragma unroll
+        for (int t = TLO; t <= THI; ++t) bv[t][ks] = bl[t * 16 * GM_LDS + ks * 4];
+    }
+#pragma unroll
+    for (int ks = 0; ks < GM_BK / 4; ++ks)
+#pragma unroll
+        for (int t = TLO; t <= THI; ++t)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][ks], bv[t][ks], acc[h][t], 0, 0, 0);
+}
+// One tile of C = A B^T from the panels Ag0 (NH * 64 rows) and Bg0 (64 rows), K range [kbeg, kend),
+// by 256 threads: wave w owns rows [16 NH w, 16 NH (w + 1)) x 64 columns as NH x 4 accumulators of
+// 16 x 16.  Operand lane maps of v_mfma_f64_16x16x4_f64: lane l supplies A[i = l & 15][k = l >> 4]
+// and B[k = l >> 4][j = l & 15]; accumulator register g of lane l is D[row = (l >> 4) + 4 g][col = l & 15].
+// K steps of GM_BK columns go through two LDS buffers (the next step's stores cannot race this
+// step's reads), the global loads of the next step are issued before this step's arithmetic.
+// TRI: B is triangular and its 64 x 64 diagonal block lies at the end (1) or at the start (2) of
+// the K range; inside that block a 16-column group of the output only meets non-zero entries in
+// the K steps on its side of the diagonal, so those four steps are peeled with fewer column
+// groups each (compile-time bounds: the accumulators then flow through straight-line code --
+// with run-time bounds the compiler merged the variants through register copies, 48 moves per
+// step, and with branches inside a step it waited for every fragment read).  TRI = 0: dense.
+template <int NH, int TRI>
+__device__ __forceinline__ void gemm_tile_acc(const double* __restrict__ Ag0,
+                                              const double* __restrict__ Bg0, int ld, int kbeg,
+                                              int kend, double* As, double* Bs,
+                                              double4_t (&acc)[NH][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int srow = tid >> 2, scol = (tid & 3) * 4;        // staging: thread t moves 4 consecutive doubles of row t / 4
     const double* Ag = Ag0 + (size_t)srow * ld + scol;
     const double* Bg = Bg0 + (size_t)srow * ld + scol;
-
-    double4_t acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    double2 a0, a1, b0, b1;
-    a0 = *reinterpret_cast<const double2*>(Ag + kbeg);
-    a1 = *reinterpret_cast<const double2*>(Ag + kbeg + 2);
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    double2 a0[NH], a1[NH], b0, b1;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        a0[h] = *reinterpret_cast<const double2*>(Ag + (size_t)h * 64 * ld + kbeg);
+        a1[h] = *reinterpret_cast<const double2*>(Ag + (size_t)h * 64 * ld + kbeg + 2);
+    }
     b0 = *reinterpret_cast<const double2*>(Bg + kbeg);
     b1 = *reinterpret_cast<const double2*>(Bg + kbeg + 2);
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
-        double* as = As + buf * (GM_BM * GM_LDS);
+    const int li = lane & 15, lk = lane >> 4;
+    const double* al = nullptr;
+    const double* bl = nullptr;
+    auto stage = [&](int k0) {
+        double* as = As + buf * (NH * 64 * GM_LDS);
         double* bs = Bs + buf * (GM_BN * GM_LDS);
-        as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
-        as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            as[(srow + 64 * h) * GM_LDS + scol + 0] = a0[h].x; as[(srow + 64 * h) * GM_LDS + scol + 1] = a0[h].y;
+            as[(srow + 64 * h) * GM_LDS + scol + 2] = a1[h].x; as[(srow + 64 * h) * GM_LDS + scol + 3] = a1[h].y;
+        }
         bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
         bs[srow * GM_LDS + scol + 2] = b1.x; bs[srow * GM_LDS + scol + 3] = b1.y;
+#ifndef GEMM_DIAG_NO_BARRIER
         __syncthreads();
-        if (k0 + GM_BK < kend) {   // prefetch the next K step while this one is multiplied
-            a0 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK);
-            a1 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK + 2);
+#endif
+#ifdef GEMM_DIAG_NO_GLOAD
+        if (k0 < 0) {
+#else
+        if (k0 + GM_BK < kend) {
+#endif
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                a0[h] = *reinterpret_cast<const double2*>(Ag + (size_t)h * 64 * ld + k0 + GM_BK);
+                a1[h] = *reinterpret_cast<const double2*>(Ag + (size_t)h * 64 * ld + k0 + GM_BK + 2);
+            }
             b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
             b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
         }
-        const int li = lane & 15, lk = lane >> 4;
-        int tlo = 0, thi = 3;                  // see gemm_tile_nt_tall
-        if (tri == 1 && k0 >= kend - GM_BN) tlo = (k0 - (kend - GM_BN)) / GM_BK;
-        if (tri == 2 && k0 < kbeg + GM_BN) thi = (k0 - kbeg) / GM_BK;
-#pragma unroll
-        for (int ks = 0; ks < GM_BK / 4; ++ks) {
-            const double av = as[(wave * 16 + li) * GM_LDS + ks * 4 + lk];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < tlo || t > thi) continue;
-                const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + lk];
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-            }
-        }
-        buf ^= 1;   // two LDS buffers: the next step's stores cannot race this step's reads
+        al = as + (wave * 16 * NH + li) * GM_LDS + lk;
+        bl = bs + li * GM_LDS + lk;
+        buf ^= 1;
+    };
+    int k0 = kbeg;
+    if constexpr (TRI == 2) {
+        stage(k0); gemm_mma_step<NH, 0, 0>(al, bl, acc); k0 += GM_BK;
+        stage(k0); gemm_mma_step<NH, 0, 1>(al, bl, acc); k0 += GM_BK;
+        stage(k0); gemm_mma_step<NH, 0, 2>(al, bl, acc); k0 += GM_BK;
     }
-    const int col = lane & 15, rq = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const size_t row = wave * 16 + rq + 4 * g;
-            Cg[row * ldc + t * 16 + col] = acc[t][g];
-        }
+    const int kfull = (TRI == 1) ? kend - GM_BN + GM_BK : kend;
+    for (; k0 < kfull; k0 += GM_BK) { stage(k0); gemm_mma_step<NH, 0, 3>(al, bl, acc); }
+    if constexpr (TRI == 1) {
+        stage(k0); gemm_mma_step<NH, 1, 3>(al, bl, acc); k0 += GM_BK;
+        stage(k0); gemm_mma_step<NH, 2, 3>(al, bl, acc); k0 += GM_BK;
+        stage(k0); gemm_mma_step<NH, 3, 3>(al, bl, acc);
     }
 }
 
-// The same tile with 128 rows: wave w owns rows [32w, 32w+32) x 64 columns as eight accumulators,
-// so every B fragment read from LDS feeds two MFMAs and a workgroup does twice the work per
-// prologue, barrier and epilogue.
-#define GM_BM2 128
-__device__ __forceinline__ void gemm_tile_nt_tall(const double* __restrict__ Ag0,
-                                                  const double* __restrict__ Bg0,
-                                                  double* __restrict__ Cg, int ld, int ldc, int kbeg,
-                                                  int kend, double* As, double* Bs, int tri) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int srow = tid >> 2;
-    const int scol = (tid & 3) * 4;
-    const double* Ag = Ag0 + (size_t)srow * ld + scol;
-    const double* Ah = Ag + (size_t)64 * ld;
-    const double* Bg = Bg0 + (size_t)srow * ld + scol;
-
-    double4_t acc[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[h][t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-    double2 a0, a1, c0, c1, b0, b1;
-    a0 = *reinterpret_cast<const double2*>(Ag + kbeg);
-    a1 = *reinterpret_cast<const double2*>(Ag + kbeg + 2);
-    c0 = *reinterpret_cast<const double2*>(Ah + kbeg);
-    c1 = *reinterpret_cast<const double2*>(Ah + kbeg + 2);
-    b0 = *reinterpret_cast<const double2*>(Bg + kbeg);
-    b1 = *reinterpret_cast<const double2*>(Bg + kbeg + 2);
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += GM_BK) {
-        double* as = As + buf * (GM_BM2 * GM_LDS);
-        double* bs = Bs + buf * (GM_BN * GM_LDS);
-        as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
-        as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
-        as[(srow + 64) * GM_LDS + scol + 0] = c0.x; as[(srow + 64) * GM_LDS + scol + 1] = c0.y;
-        as[(srow + 64) * GM_LDS + scol + 2] = c1.x; as[(srow + 64) * GM_LDS + scol + 3] = c1.y;
-        bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
-        bs[srow * GM_LDS + scol + 2] = b1.x; bs[srow * GM_LDS + scol + 3] = b1.y;
-        __syncthreads();
-        if (k0 + GM_BK < kend) {   // prefetch the next K step while this one is multiplied
-            a0 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK);
-            a1 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK + 2);
-            c0 = *reinterpret_cast<const double2*>(Ah + k0 + GM_BK);
-            c1 = *reinterpret_cast<const double2*>(Ah + k0 + GM_BK + 2);
-            b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
-            b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
-        }
-        const int li = lane & 15, lk = lane >> 4;
-        // inside the 64 x 64 diagonal block of the triangular operand a 16-column group of the
-        // output only meets non-zero entries in the K steps on its side of the diagonal
-        int tlo = 0, thi = 3;
-        if (tri == 1 && k0 >= kend - GM_BN) tlo = (k0 - (kend - GM_BN)) / GM_BK;
-        if (tri == 2 && k0 < kbeg + GM_BN) thi = (k0 - kbeg) / GM_BK;
-#pragma unroll
-        for (int ks = 0; ks < GM_BK / 4; ++ks) {
-            const double av0 = as[(wave * 32 + li) * GM_LDS + ks * 4 + lk];
-            const double av1 = as[(wave * 32 + 16 + li) * GM_LDS + ks * 4 + lk];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < tlo || t > thi) continue;
-                const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + lk];
-                acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv, acc[1][t], 0, 0, 0);
-            }
-        }
-        buf ^= 1;
-    }
+// stores a wave's accumulators to the output tile (leading dimension ldc)
+template <int NH>
+__device__ __forceinline__ void gemm_tile_store(double* __restrict__ Cg, int ldc, const double4_t (&acc)[NH][4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const size_t row = wave * 32 + h * 16 + rq + 4 * g;
+                const size_t row = wave * 16 * NH + h * 16 + rq + 4 * g;
+#ifdef GEMM_DIAG_NO_STORE
+                if (acc[h][t][g] == 123.456)
+#endif
                 Cg[row * ldc + t * 16 + col] = acc[h][t][g];
             }
+}
+
+// Ag/Bg point at the first row of the two operand panels (leading dimension ld, K along the row);
+// Cg at the output tile (leading dimension ldc).  64 x 64 tile.
+template <int TRI>
+__device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
+                                             const double* __restrict__ Bg0,
+                                             double* __restrict__ Cg, int ld, int ldc, int kbeg,
+                                             int kend, double* As, double* Bs) {
+    double4_t acc[1][4];
+    gemm_tile_acc<1, TRI>(Ag0, Bg0, ld, kbeg, kend, As, Bs, acc);
+    gemm_tile_store<1>(Cg, ldc, acc);
+}
+
+// The same with a 128-row A panel whose wave layout is 32 rows per wave: every B fragment read from
+// LDS feeds two MFMAs and a workgroup does twice the work per prologue, barrier and epilogue.
+#define GM_BM2 128
+template <int TRI>
+__device__ __forceinline__ void gemm_tile_nt_tall(const double* __restrict__ Ag0,
+                                                  const double* __restrict__ Bg0,
+                                                  double* __restrict__ Cg, int ld, int ldc, int kbeg,
+                                                  int kend, double* As, double* Bs) {
+    double4_t acc[2][4];
+    gemm_tile_acc<2, TRI>(Ag0, Bg0, ld, kbeg, kend, As, Bs, acc);
+    gemm_tile_store<2>(Cg, ldc, acc);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_nt_tall(const double* __restrict__ A,
@@ -316,7 +321,12 @@ __global__ __launch_bounds__(256) void k_gemm_nt_tall(const double* __restrict__
     const size_t r0 = rb * GM_BM2;
     const int kbeg = lower ? 0 : j0;
     const int kend = lower ? (j0 + GM_BN) : npad;
-    gemm_tile_nt_tall(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs, lower ? 1 : 2);
+#ifdef OEI_GEMM_DENSE_TIMING        // diagnostic: every tile with the full K range (wrong results)
+    gemm_tile_nt_tall<0>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, 0, npad, As, Bs);
+    return;
+#endif
+    if (lower) gemm_tile_nt_tall<1>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+    else gemm_tile_nt_tall<2>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
 }
 
 __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
@@ -336,7 +346,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
     const size_t r0 = rb * GM_BM;
     const int kbeg = lower ? 0 : j0;
     const int kend = lower ? (j0 + GM_BN) : npad;
-    gemm_tile_nt(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs, lower ? 1 : 2);
+    if (lower) gemm_tile_nt<1>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+    else gemm_tile_nt<2>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
 }
 
 int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,
@@ -399,8 +410,6 @@ __global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const size_t r0 = (size_t)rb * GM_BM;
-    const int srow = tid >> 2, scol = (tid & 3) * 4;
-    const double* Ag = Z + (r0 + srow) * npad + scol;
     size_t rows[4];
     double pr[4];
 #pragma unroll
@@ -413,50 +422,16 @@ __global__ __launch_bounds__(256, 3) void k_gemm_grad(const double* __restrict__
 
     {
         const int j0 = (int)split * GM_BN;
-        const double* Bg = LinvT + (size_t)(j0 + srow) * npad + scol;
-        double4_t acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        double2 a0, a1, b0, b1;
-        a0 = *reinterpret_cast<const double2*>(Ag + j0);
-        a1 = *reinterpret_cast<const double2*>(Ag + j0 + 2);
-        b0 = *reinterpret_cast<const double2*>(Bg + j0);
-        b1 = *reinterpret_cast<const double2*>(Bg + j0 + 2);
         __syncthreads();                 // the previous tile's readers of As/Bs/Xs are done
         for (int e = tid; e < 64 * dp; e += 256) {
             const int k = e / dp, l = e - k * dp;
             Xs[k * (DPM + 1) + l] = (l < d) ? Xtrain[(size_t)(j0 + k) * d + l] : 1.0;
         }
-        int buf = 0;
-        for (int k0 = j0; k0 < npad; k0 += GM_BK) {
-            double* as = As + buf * (GM_BM * GM_LDS);
-            double* bs = Bs + buf * (GM_BN * GM_LDS);
-            as[srow * GM_LDS + scol + 0] = a0.x; as[srow * GM_LDS + scol + 1] = a0.y;
-            as[srow * GM_LDS + scol + 2] = a1.x; as[srow * GM_LDS + scol + 3] = a1.y;
-            bs[srow * GM_LDS + scol + 0] = b0.x; bs[srow * GM_LDS + scol + 1] = b0.y;
-            bs[srow * GM_LDS + scol + 2] = b1.x; bs[srow * GM_LDS + scol + 3] = b1.y;
-            __syncthreads();
-            if (k0 + GM_BK < npad) {
-                a0 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK);
-                a1 = *reinterpret_cast<const double2*>(Ag + k0 + GM_BK + 2);
-                b0 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK);
-                b1 = *reinterpret_cast<const double2*>(Bg + k0 + GM_BK + 2);
-            }
-            // L^-T is upper triangular: in the diagonal block (the first four K steps) column
-            // group t of the tile only meets non-zero entries from K step t on
-            const int thi = (k0 < j0 + GM_BN) ? (k0 - j0) / GM_BK : 3;
-#pragma unroll
-            for (int ks = 0; ks < GM_BK / 4; ++ks) {
-                const double av = as[(wave * 16 + li) * GM_LDS + ks * 4 + kg];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (t > thi) continue;
-                    const double bv = bs[(t * 16 + li) * GM_LDS + ks * 4 + kg];
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-                }
-            }
-            buf ^= 1;
-        }
+        // L^-T is upper triangular: in the diagonal block (the first four K steps) column group t
+        // of the tile only meets non-zero entries from K step t on
+        double4_t acc1[1][4];
+        gemm_tile_acc<1, 2>(Z + r0 * npad, LinvT + (size_t)j0 * npad, npad, j0, npad, As, Bs, acc1);
+        double4_t (&acc)[4] = acc1[0];
         // contraction of the W tile (Xs was published by the barriers of the K loop), two of the
         // lane's four rows at a time to keep the register count at four waves per SIMD
 #pragma unroll
@@ -585,7 +560,7 @@ __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
     if (used - I * 64 <= 16)
         gemm_tile_nt_strip16(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, npad, As, Bs);
     else
-        gemm_tile_nt(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, 0, npad, As, Bs, 0);
+        gemm_tile_nt<0>(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, 0, npad, As, Bs);
 }
 
 int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st, int used) {
