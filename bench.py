@@ -6,7 +6,10 @@
 One step = one pass of the hot path over one batch of synthetic candidate batches already resident
 in HBM: value + gradient of B candidates (q=20, d=6) under the n=310 hart6 GP, the local arg-min
 and, for N > 1, the all-gather of the (value, index, X) record that picks the best start.  Work per
-GPU is fixed (weak scaling).  Rank 0 prints ONE JSON line.
+GPU is fixed (weak scaling).  Rank 0 prints ONE JSON line.  Order inside a rank: model, Hessian
+throughput leg (untimed; heavy GPU work that also leaves the clocks up), W warm-up steps, barrier,
+K timed steps, barrier; then the profiled calls for the roofline, the callers' legs and the CPU
+baseline.
 
 With --gpus N > 1 and no WORLD_SIZE in the environment this process only launches: it starts N
 ranks of itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1),
@@ -226,6 +229,23 @@ def main():
 
         sync = torch.cuda.synchronize
 
+    # Hessian throughput of the same model and candidates (second half of the metric), outside the
+    # timed region and ahead of it: a few calls on a slice of this rank's candidates.  Every rank
+    # runs it, so that all of them enter the timed steps with the clocks the preceding work left
+    # (a run with a handful of warm-up steps otherwise times the clock ramp after the idle set-up).
+    hess_timing = None
+    if not cpu_only and not args.no_hessian:
+        hb = min(B, 2048)
+        hreps = 20
+        for _ in range(5):                      # buffers, then clocks
+            gp.hessian(X_local[:hb])
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(hreps):
+            _, hst = gp.hessian(X_local[:hb])
+        torch.cuda.synchronize()
+        hess_timing = (hb, hreps, (time.perf_counter() - th) / hreps, int((hst != 0).sum().item()))
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -301,8 +321,8 @@ def main():
                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic,
                         'peak_note': 'fp64 vector peak = fp64 matrix peak on MI355X; two thirds of the '
                                      "kernel's flops and nearly all of its time are vector arithmetic",
-                        'sustained_note': 'a memory-free loop on this chip sustains 56-58 TFLOP/s of v_fma_f64 and 48-49 '
-                                          'TFLOP/s of v_mfma_f64_16x16x4 (tools/micro/mfma_peak.hip); the GEMM stages run at 47',
+                        'sustained_note': 'memory-free loops on this chip sustain 59 TFLOP/s of v_fma_f64 (two waves per SIMD) and 77 '
+                                          'TFLOP/s of v_mfma_f64_16x16x4 at any occupancy (tools/micro/mixed_pipes.hip, mfma_occupancy.hip)',
                         'launch_ms': sdp_ms, 'flops_per_launch': fl,
                         'launch_ms_note': 'HIP events attached to the dispatch of k_stage2 on its stream (hipExtLaunchKernel), '
                                           'mean of %d whole-batch launches on one stream; stage_ms are intervals between '
@@ -313,23 +333,12 @@ def main():
                         'stage_ms': dict(zip(names, [float(x) for x in stage])),
                         'dominant_stage': names[dom],
                         'newton_iters_mean': float(newton.mean()), 'jacobi_sweeps_mean': float(sweeps.mean())}
-            # Hessian throughput of the same model and candidates (second half of the metric), outside
-            # the timed region: a few calls on a slice of this rank's candidates
-            if not args.no_hessian:
-                hb = min(B, 2048)
-                hreps = 20
-                for _ in range(5):                      # buffers, then clocks
-                    gp.hessian(X_local[:hb])
-                torch.cuda.synchronize()
-                th = time.perf_counter()
-                for _ in range(hreps):
-                    _, hst = gp.hessian(X_local[:hb])
-                torch.cuda.synchronize()
-                th = (time.perf_counter() - th) / hreps
+            if hess_timing is not None:
+                hb, hreps, th, h_unsolved = hess_timing
                 hfl = hessian_flops_model(q, d, n, gp.n + (-gp.n) % 64, fl / B)
                 hfl_exec = hessian_flops_model(q, d, n, gp.n + (-gp.n) % 64, fl / B, executed=True)
                 hessian = {'value': hb / th, 'unit': 'Hessians/s (one GPU)', 'candidates_per_call': hb,
-                           'ms_per_call': th * 1e3, 'unsolved': int((hst != 0).sum().item()),
+                           'ms_per_call': th * 1e3, 'unsolved': h_unsolved,
                            'roofline': {'bound': 'fp64 (MFMA front end, vector-unit directions)',
                                         'flops_per_hessian': hfl, 'flops_per_hessian_executed': hfl_exec,
                                         'achieved': hfl * hb / th / 1e12,
