@@ -82,7 +82,8 @@ int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t ro
     return OEI_OK;
 }
 
-// Extended rows for the Hessian path.  Candidate b owns rows [b*RP, (b+1)*RP):
+// Extended rows for the Hessian path.  Candidate b owns rows [b*RP, (b+1)*RP) (RP a multiple of 16;
+// the blocks are packed densely, so a workgroup takes a group of up to GR_ROWS rows of ONE block):
 //   r = a*(d+1)       -> k(x_a, X_k)
 //   r = a*(d+1)+1+l   -> d k(x_a, X_k) / d x_a[l]
 //   r = q*(d+1)       -> y_k            (becomes v = L^-1 y after the GEMM)
@@ -98,9 +99,10 @@ __global__ __launch_bounds__(256) void k_gram_ext(KernParams kp, const double* _
     double* Qs = sm + 64 * d;        // [GR_ROWS][d]
     const int tid = threadIdx.x;
     const int k0 = blockIdx.y * 64;
-    const size_t r0 = (size_t)blockIdx.x * GR_ROWS;      // RP is a multiple of GR_ROWS
-    const size_t b = r0 / RP;
-    const int rl0 = (int)(r0 - b * RP);
+    const int ngrp = (RP + GR_ROWS - 1) / GR_ROWS;
+    const size_t b = blockIdx.x / ngrp;
+    const int rl0 = (int)(blockIdx.x - b * ngrp) * GR_ROWS;
+    const int rlim = min(rl0 + GR_ROWS, RP);              // rows [rl0, rlim) of block b
     for (int i = tid; i < 64 * d; i += 256) {
         int k = k0 + i / d;
         Xs[i] = (k < n) ? Xtrain[(size_t)k * d + (i % d)] : 0.0;
@@ -115,9 +117,9 @@ __global__ __launch_bounds__(256) void k_gram_ext(KernParams kp, const double* _
     // One kernel evaluation per (point, training point) serves the point's value row and its d
     // derivative rows (they share t and the exponential); a point whose rows straddle two row
     // groups is evaluated by both.  Wave w takes every fourth point of the group.
-    const int a_lo = rl0 / dp, a_hi = (rl0 + GR_ROWS - 1) / dp;
+    const int a_lo = rl0 / dp, a_hi = (rlim - 1) / dp;
     for (int a = a_lo + (tid >> 6); a <= a_hi; a += 4) {
-        const int rbeg = max(a * dp, rl0), rend = min(a * dp + dp, rl0 + GR_ROWS);     // rows [rbeg, rend)
+        const int rbeg = max(a * dp, rl0), rend = min(a * dp + dp, rlim);     // rows [rbeg, rend)
         if (a < q && k < n) {
             const double* xa = Qs + (rbeg - rl0) * d;    // every row of the group carries its point
             double t = 0.0;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gram_ext(KernParams kp, const double* _
 
 int oei_launch_gram_ext(const oei_model* m, const double* Xq, int B, int q, int RP, double* out,
                         hipStream_t st) {
-    dim3 grid((unsigned)((size_t)B * RP / GR_ROWS), m->npad / 64);
+    dim3 grid((unsigned)((size_t)B * ((RP + GR_ROWS - 1) / GR_ROWS)), m->npad / 64);
     size_t lds = (size_t)(64 + GR_ROWS) * m->d * sizeof(double);
     hipLaunchKernelGGL(k_gram_ext, grid, dim3(256), lds, st, m->kp, m->X, m->y, m->n, m->npad, Xq, q, RP, out);
     OEI_HIP_CHECK(hipGetLastError());
@@ -264,9 +266,11 @@ __device__ __forceinline__ void gemm_tile_acc(const double* __restrict__ Ag0,
     }
 }
 
-// stores a wave's accumulators to the output tile (leading dimension ldc)
+// stores a wave's accumulators to the output tile (leading dimension ldc); rows / columns of the
+// tile at and past rlim / clim are not written
 template <int NH>
-__device__ __forceinline__ void gemm_tile_store(double* __restrict__ Cg, int ldc, const double4_t (&acc)[NH][4]) {
+__device__ __forceinline__ void gemm_tile_store(double* __restrict__ Cg, int ldc, const double4_t (&acc)[NH][4],
+                                                int rlim = 64 * NH, int clim = 64) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
@@ -276,7 +280,7 @@ __device__ __forceinline__ void gemm_tile_store(double* __restrict__ Cg, int ldc
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const size_t row = wave * 16 * NH + h * 16 + rq + 4 * g;
-                Cg[row * ldc + t * 16 + col] = acc[h][t][g];
+                if ((int)row < rlim && t * 16 + col < clim) Cg[row * ldc + t * 16 + col] = acc[h][t][g];
             }
 }
 
@@ -286,10 +290,10 @@ template <int TRI>
 __device__ __forceinline__ void gemm_tile_nt(const double* __restrict__ Ag0,
                                              const double* __restrict__ Bg0,
                                              double* __restrict__ Cg, int ld, int ldc, int kbeg,
-                                             int kend, double* As, double* Bs) {
+                                             int kend, double* As, double* Bs, int rlim = 64, int clim = 64) {
     double4_t acc[1][4];
     gemm_tile_acc<1, TRI>(Ag0, Bg0, ld, kbeg, kend, As, Bs, acc);
-    gemm_tile_store<1>(Cg, ldc, acc);
+    gemm_tile_store<1>(Cg, ldc, acc, rlim, clim);
 }
 
 // The same with a 128-row A panel whose wave layout is 32 rows per wave: every B fragment read from
@@ -473,11 +477,11 @@ int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, 
 // The 64 x 64 tile when only the first 16 rows of the A panel hold data (the last row tile of a
 // block whose row count is just past a multiple of 64): the four waves share those 16 rows and
 // take one 16-column group each, a quarter of the matrix instructions per wave.  Rows 16..63 of the
-// output tile are not written (padding rows of the block, which nothing reads).
+// output tile are not written (they are not rows of this block), nor are columns at and past clim.
 __device__ __forceinline__ void gemm_tile_nt_strip16(const double* __restrict__ Ag0,
                                                      const double* __restrict__ Bg0,
                                                      double* __restrict__ Cg, int ld, int ldc,
-                                                     int kend, double* As, double* Bs) {
+                                                     int kend, double* As, double* Bs, int clim = 64) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int srow = tid >> 2, scol = (tid & 3) * 4;
     const double* Ag = Ag0 + (size_t)(srow & 15) * ld + scol;      // only 16 A rows are staged (four times over)
@@ -516,12 +520,15 @@ __device__ __forceinline__ void gemm_tile_nt_strip16(const double* __restrict__ 
     }
     const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Cg[(size_t)(rq + 4 * g) * ldc + wave * 16 + col] = acc[g];
+    for (int g = 0; g < 4; ++g)
+        if (wave * 16 + col < clim) Cg[(size_t)(rq + 4 * g) * ldc + wave * 16 + col] = acc[g];
 }
 
 // G_b = E_b E_b^T for every candidate: lower block-triangle of 64x64 tiles, tile index t of
-// blockIdx.y enumerates (I >= J).  E [B*RP, npad], G [B, RP, RP].  `used`: rows of a block that
-// hold data (the rest are zero rows).
+// blockIdx.y enumerates (I >= J).  E [B*RP, npad] with the blocks packed densely (RP a multiple of
+// 16, not of 64: the last tile of a block is partial, and what a panel reads past the block's rows
+// -- the next block, or the slack behind the last one -- lands in rows and columns that are not
+// stored), G [B, RP, RP].  `used`: rows of a block that hold data (the rest are zero rows).
 __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
                                                   double* __restrict__ G, int RP, int npad, int used) {
     __shared__ __attribute__((aligned(16))) double As[2 * GM_BM * GM_LDS];
@@ -532,14 +539,15 @@ __global__ __launch_bounds__(256) void k_gram_blk(const double* __restrict__ E,
     const int J = t - I * (I + 1) / 2;
     const double* Eb = E + b * (size_t)RP * npad;
     double* Gt = G + b * (size_t)RP * RP + (size_t)I * 64 * RP + J * 64;
+    const int rlim = min(64, RP - 64 * I), clim = min(64, RP - 64 * J);
     if (used - I * 64 <= 16)
-        gemm_tile_nt_strip16(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, npad, As, Bs);
+        gemm_tile_nt_strip16(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, npad, As, Bs, clim);
     else
-        gemm_tile_nt<0>(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, 0, npad, As, Bs);
+        gemm_tile_nt<0>(Eb + (size_t)I * 64 * npad, Eb + (size_t)J * 64 * npad, Gt, npad, RP, 0, npad, As, Bs, rlim, clim);
 }
 
 int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hipStream_t st, int used) {
-    const int nt = RP / 64;
+    const int nt = (RP + 63) / 64;
     if (used <= 0 || used > RP) used = RP;
     dim3 grid((unsigned)B, nt * (nt + 1) / 2);
     hipLaunchKernelGGL(k_gram_blk, grid, dim3(256), 0, st, E, G, RP, npad, used);

@@ -1010,8 +1010,10 @@ static int check_call(const oei_model* m, int B, int q, const void* X, const voi
 // gram_ext -> GEMM -> Gram blocks for candidates [0, Bc): E in ws1, G at m->hs.
 static int hess_front(oei_model* m, int Bc, int q, const double* X, int RP, size_t extra_bytes,
                       hipStream_t st) {
-    const size_t rows = (size_t)Bc * RP;
-    int rc = oei_ws_reserve(m, rows, ((size_t)Bc * q + (size_t)Bc * q * q) * sizeof(double));
+    // the blocks are packed densely (RP is a multiple of 16); the GEMM runs on whole 128-row tiles
+    // and the last block's partial Gram tiles read up to 64 rows past it: slack rows behind the data
+    const size_t rows = round_up_sz((size_t)Bc * RP, 128);
+    int rc = oei_ws_reserve(m, rows + 64, ((size_t)Bc * q + (size_t)Bc * q * q) * sizeof(double));
     if (rc) return rc;
     const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
     if ((rc = hs_reserve(m, gbytes + extra_bytes))) return rc;
@@ -1028,7 +1030,7 @@ extern "C" int oei_domega_batched(oei_model* m, int B, int q, const double* X, d
     if (B == 0) return OEI_OK;
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d, qd = q * d, k_ = q + 1;
-    const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
+    const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 16);
     const size_t lds = ((size_t)2 * qd + q + (size_t)q * q) * sizeof(double);
     const int chunk = 512;
     for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -1055,7 +1057,7 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
     if (B == 0) return OEI_OK;
     hipStream_t st = (hipStream_t)stream;
     const int d = m->d, qd = q * d, npad = m->npad;
-    const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 64);
+    const int RP = (int)round_up_sz((size_t)q * (d + 1) + 1, 16);
     const size_t lds = hess_wide_lds_doubles(q, d) * sizeof(double);     // wide kernel only
     // q <= 32 runs on the register-path kernels while a candidate's tables fit in LDS beside one
     // wave's scratch matrices; past that (q near 32 with d >= 9) the wide kernel, which keeps the

@@ -253,6 +253,10 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     lds_f64* Ta = w.X;
     lds_f64* Tb = w.V;
     lds_f64* Tc = w.Kt;
+    // row index of entry e of a q x q pass without an integer division (q is a run-time value
+    // here: the division is some forty instructions per entry): exact for e < 4096, q <= 64
+    const float rq = 1.0f / (float)q;
+    auto row_of = [&](int e) { return QE > 0 ? e / QE : (int)(((float)e + 0.5f) * rq); };
     sens_sync<WAVE>();
     if constexpr (RANK2) {
         // U^T dS U = u wv^T + wv u^T with u = row a of U, wv = U^T v'
@@ -265,7 +269,7 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
         }
         const lds_f64* ua = U + sd.a * LD;
         for (int e = tid; e < q * q; e += TT) {            // ZS
-            const int a = e / q, b = e - a * q;
+            const int a = row_of(e), b = e - a * q;
             Tc[a * LD + b] = (ua[a] * sd.wv[b] + sd.wv[a] * ua[b]) * sd.phiS[a * LD + b];
         }
     } else {
@@ -274,7 +278,7 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
         sens_mm<T, WAVE, true, false, false>(tid, q, LD, U, Tb, Tc);             // Tc = U^T dS U
         sens_sync<WAVE>();
         for (int e = tid; e < q * q; e += TT) {            // ZS
-            const int a = e / q, b = e - a * q;
+            const int a = row_of(e), b = e - a * q;
             const double sa = w.sq[a], sb = w.sq[b];
             Tc[a * LD + b] *= sd.phiS ? sd.phiS[a * LD + b] : -0.5 * sdp_rcp(sa * sb * (sa + sb));
         }
@@ -340,7 +344,7 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
     sens_mm<T, WAVE, true, false, true>(tid, q, LD, w.R, w.R, Tb, sv.dp);   // Tb = R^T diag(dp) R
     sens_sync<WAVE>();
     for (int e = tid; e < q * q; e += TT) {               // Z = ZS + Phi o (R^T dD R)/4
-        const int a = e / q, b = e - a * q;
+        const int a = row_of(e), b = e - a * q;
         const double acc = Tb[a * LD + b] - sv.rd[a] * w.rp[b] - w.rp[a] * sv.rd[b];
         Tc[a * LD + b] += acc * (sd.phiD ? sd.phiD[a * LD + b] : 0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
