@@ -80,7 +80,12 @@ __global__ __launch_bounds__(T) void k_soldiff(int q, int K, const double* __res
             const double dO = 0.5 * (dOb[((size_t)i * k_ + l) * K + j] + dOb[((size_t)l * k_ + i) * K + j]);
             w.X[i * LD + l] = (dO - Sc[i * LD + l] * dw0) / w0 - sv.dmu[i] * mu[l] - mu[i] * sv.dmu[l];
         }
+#ifdef OEI_HESS_TIMING
+        long long sens_cyc[12] = {};
+        const double dnu = sens_direction<T, T == 64, false>(w, sv, SensDir{0, nullptr, nullptr, nullptr, nullptr}, sens_cyc);
+#else
         const double dnu = sens_direction<T, T == 64, false>(w, sv, SensDir{0, nullptr, nullptr, nullptr, nullptr});
+#endif
         for (int e = tid; e < k_ * k_; e += T) {
             const int i = e / k_, l = e - i * k_;
             double val;
@@ -756,7 +761,7 @@ __host__ __device__ inline size_t hess_state_doubles(int q) {
 }
 
 template <int T, int Q>
-__global__ __launch_bounds__(T) void k_hess_prep(KernParams kp, double noise, double fmin, int q,
+__global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_hess_prep(KernParams kp, double noise, double fmin, int q,
                                                  int RP, const double* __restrict__ Xq,
                                                  const double* __restrict__ G,
                                                  const double* __restrict__ p_in,
@@ -765,9 +770,9 @@ __global__ __launch_bounds__(T) void k_hess_prep(KernParams kp, double noise, do
     extern __shared__ __attribute__((aligned(16))) double sm[];
     OEI_LDS_POISON(sm);
     SdpWork w;
-    sdp_carve(w, sm, q, true);
+    sdp_carve(w, sm, q, true, sdp_mm<Q>());
     const int VL = sdp_vlen(q), LD = w.LD, d = kp.d, dp = d + 1, qd = q * d;
-    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, true);
+    lds_f64* mu = (lds_f64*)sm + sdp_work_doubles(q, true, sdp_mm<Q>());
     SensVec sv;
     sens_carve(sv, mu + VL, q);
     lds_f64* xq = mu + VL + SENS_NVEC * VL;      // [q*d]
@@ -844,6 +849,9 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
                                                  double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     OEI_LDS_POISON(sm);
+#ifdef OEI_HESS_TIMING
+    const long long t_kernel0 = clock64();
+#endif
     constexpr int NW = T / 64;
     const int q = QE > 0 ? QE : q_arg;           // QE > 0: instance for exactly this q
     const int VL = sdp_vlen(q), LD = sdp_ld(q), ML = q * LD, d = kp.d, qd = q * d;
@@ -966,6 +974,11 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     sv.dc = wv0 + 4 * VL;    sv.w1 = wv0 + 5 * VL;  sv.w2 = wv0 + 6 * VL;
     lds_f64* dNmu = wv0 + 7 * VL;
     sv.c = cv; sv.t1 = t1;
+#ifdef OEI_HESS_TIMING
+    long long sens_cyc[12] = {};
+    const long long t_dirs0 = clock64();
+    sens_cyc[11] = t_dirs0 - t_kernel0;
+#endif
     for (int al = wave + NW * slice; al < qd; al += NW * nslice) {
         const int a = al / d, l = al - a * d;
         sens_sync<true>();
@@ -977,12 +990,25 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
             ttpre[u] = gsym(Gb, RP, a * (d + 1) + 1 + l, bb * (d + 1) + 1 + m2);
         }
         if (lane < q) sv.dmu[lane] = (lane == a) ? dmuT[al] : 0.0;
+#ifdef OEI_HESS_TIMING
+        sens_direction<64, true, true, QE, true, true>(w, sv, SensDir{a, nullptr, tab + (size_t)al * q, phiS, phiD, utc}, sens_cyc);
+        long long sens_t0 = clock64();
+#else
         sens_direction<64, true, true, QE, true, true>(w, sv, SensDir{a, nullptr, tab + (size_t)al * q, phiS, phiD, utc});
+#endif
         if (lane < q) dNmu[lane] = lds_dot(w.V + lane * LD, 1, utmu, 1, q);      // dN mu = Y (U^T mu)
         sens_sync<true>();
         hess_contract<true>(lane, 64, kp, q, RP, a, l, w.V, LD, DS, dmuT, sv.w1, sv.w2, dNmu, Gb, (const lds_f64*)M11, xq,
                       (const lds_f64*)k1s, (const lds_f64*)k2s, (const lds_f64*)Dg, Hb, ttpre);
+        SENS_STAMP(7);
     }
+#ifdef OEI_HESS_TIMING
+    // diagnostic build: the cycle counts of this wave overwrite the first entries of the output
+    sens_cyc[10] = clock64() - t_dirs0;
+    __syncthreads();
+    if (b == 0 && slice == 0 && tid == 0)
+        for (int i = 0; i < 12; ++i) Hb[i] = (double)sens_cyc[i];
+#endif
     // a solve that stopped at the Newton iteration limit (status 1) still gets its Hessian
     if (slice == 0 && tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;
 }
@@ -1099,9 +1125,13 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
             // state + flags behind the buffers already carved from m->hs
             double* state = reinterpret_cast<double*>(stb + ((Bc + 1) & ~1));
             int* pflag = reinterpret_cast<int*>(state + (size_t)Bc * hess_state_doubles(q));
-            const size_t lds_prep = (sdp_work_doubles(q, true) + (size_t)(1 + SENS_NVEC) * sdp_vlen(q) + (size_t)qd) * sizeof(double);
-            if ((rc = set_lds_attr((k_hess_prep<64, 32>), lds_prep))) return rc;
-            hipLaunchKernelGGL((k_hess_prep<64, 32>), dim3(Bc), dim3(64), lds_prep, st, m->kp, m->noise, m->fmin, q, RP, Xc, m->hs, p_buf, state, pflag);
+            // the solver instance of the candidate's size, as in the value + gradient path
+#define LAUNCH_PREP(T_, Q_) do { \
+                const size_t lds_prep = (sdp_work_doubles(q, true, sdp_mm<Q_>()) + (size_t)(1 + SENS_NVEC) * sdp_vlen(q) + (size_t)qd) * sizeof(double); \
+                if ((rc = set_lds_attr((k_hess_prep<64, (Q_) ? (Q_) : 32>), lds_prep))) return rc; \
+                hipLaunchKernelGGL((k_hess_prep<64, (Q_) ? (Q_) : 32>), dim3(Bc), dim3(64), lds_prep, st, m->kp, m->noise, m->fmin, q, RP, Xc, m->hs, p_buf, state, pflag); } while (0)
+            SDP_DISPATCH_Q(q, LAUNCH_PREP);
+#undef LAUNCH_PREP
             OEI_HIP_CHECK(hipGetLastError());
             const size_t shared = hess_dirs_shared_doubles(q, d) * sizeof(double), per_wave = hess_dirs_wave_doubles(q) * sizeof(double);
             const size_t budget = 160 * 1024;

@@ -244,8 +244,20 @@ struct SensDir {
 // LINV (one wave): w.H holds L^-1 as a full matrix (zeros above the diagonal) instead of L, and
 // the two triangular solves become two matrix-vector products -- 2 q multiply-adds per lane with
 // no chain through the scalar unit, against 2 q dependent broadcast steps.
+#ifdef OEI_HESS_TIMING
+#define SENS_STAMP(i) do { const long long t_ = clock64(); sens_cyc[i] += t_ - sens_t0; sens_t0 = t_; } while (0)
+#else
+#define SENS_STAMP(i) do { } while (0)
+#endif
 template <int T, bool WAVE, bool RANK2, int QE = 0, bool YFORM = false, bool LINV = false>
-__device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec sv, const SensDir sd) {
+__device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec sv, const SensDir sd
+#ifdef OEI_HESS_TIMING
+                                                 , long long (&sens_cyc)[12]
+#endif
+                                                 ) {
+#ifdef OEI_HESS_TIMING
+    long long sens_t0 = clock64();
+#endif
     constexpr int TT = WAVE ? 64 : T;
     const int tid = WAVE ? (threadIdx.x & 63) : threadIdx.x;
     const int q = QE > 0 ? QE : w.q, LD = QE > 0 ? (QE | 1) : w.LD;
@@ -284,11 +296,13 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
         }
     }
     sens_sync<WAVE>();
+    SENS_STAMP(0);
     // rhs = dmu - (dBS_ii - 2 (dBS p)_i)/4 with dBS = -4 Rs ZS Rs^T, Rs = R diag(sq):
     // M1 = ZS Rs^T (into Tb), t2 = ZS t1, rhs_i = dmu_i + sum_a Rs[i][a] (M1[a][i] - 2 t2[a])
     sens_mm<T, WAVE, false, true, true>(tid, q, LD, Tc, w.R, Tb, w.sq);
     if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);
     sens_sync<WAVE>();
+    SENS_STAMP(1);
     double rhs = 0.0;
     if (tid < q) rhs = sv.dmu[tid] + lds_dot_rs(w.R + tid * LD, w.sq, Tb + tid, LD, sv.t2, q);
     // A x = rhs with A = L L^T = -hess g
@@ -340,15 +354,18 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
         if (tid < q) sv.dp[tid] = -w.step[tid];
     }
     sens_sync<WAVE>();
+    SENS_STAMP(2);
     if (tid < q) sv.rd[tid] = lds_dot(w.R + tid, LD, sv.dp, 1, q);
     sens_mm<T, WAVE, true, false, true>(tid, q, LD, w.R, w.R, Tb, sv.dp);   // Tb = R^T diag(dp) R
     sens_sync<WAVE>();
+    SENS_STAMP(3);
     for (int e = tid; e < q * q; e += TT) {               // Z = ZS + Phi o (R^T dD R)/4
         const int a = row_of(e), b = e - a * q;
         const double acc = Tb[a * LD + b] - sv.rd[a] * w.rp[b] - w.rp[a] * sv.rd[b];
         Tc[a * LD + b] += acc * (sd.phiD ? sd.phiD[a * LD + b] : 0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
     sens_sync<WAVE>();
+    SENS_STAMP(4);
     if constexpr (YFORM) {
         sens_mm<T, WAVE, false, false, false>(tid, q, LD, U, Tc, Tb);        // Tb = Y = U Z
         if (tid < q) sv.t2[tid] = lds_dot(Tc + tid * LD, 1, sv.t1, 1, q);     // Z t1
@@ -359,6 +376,7 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
         sens_sync<WAVE>();
         sens_mm<T, WAVE, false, false, false>(tid, q, LD, U, Tb, Ta);        // Ta = dN = U Z U^T
     }
+    SENS_STAMP(5);
     // dc = dmu + (dB p + B dp)/2 = dmu - 2 Rs (Z t1) + R (sq o rd)
     if (tid < q) sv.dc[tid] = sv.dmu[tid] + lds_dot_rs(w.R + tid * LD, w.sq, sv.rd, 1, sv.t2, q);
     sens_sync<WAVE>();
@@ -370,6 +388,7 @@ __device__ __forceinline__ double sens_direction(const SdpWork w, const SensVec 
                            : lds_dot(Ta + tid * LD, 1, sv.c, 1, q);    // dN c
     }
     sens_sync<WAVE>();
+    SENS_STAMP(6);
     double dnu = 0.0;
     for (int i = 0; i < q; ++i) dnu += sv.c[i] * (2.0 * sv.w1[i] + sv.w2[i]);
     return dnu;
