@@ -362,17 +362,25 @@ __device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int
 // training points lane (i, kk) supplies c2[a,k] diff and diff (k = 4 s + kk), the same index
 // pattern on both sides, so one LDS read pair feeds both operands; the diagonal blocks of the tile
 // are the wanted sums, the off-diagonal blocks (products across points) are ignored.  The tile
-// accumulates over all training points in registers.  Chunk length: the multiple of four that
-// minimises kernel-evaluation passes over the workgroup.  What a thread's first staging element
-// and first evaluation read from global memory is fetched one chunk ahead, so that its latency
-// passes behind the previous chunk's work.  Leaves a barrier behind.
+// accumulates over all training points in registers.  The training inputs are staged in `tab` once
+// per workgroup when they fit (n ((d + 1) | 1) <= tabsz; else per wave and chunk); after that every
+// wave works alone on its points, in chunks of up to 128 training points whose coefficients go
+// through its own scratch (`wsz` doubles): kernel derivatives of the chunk's (point, training
+// point) pairs by the 64 lanes, four pairs per lane at a time so that their global loads are in
+// flight together, then the matrix instructions.  No workgroup barrier inside the pass.  (With
+// chunks of 36 staged per workgroup the pass was three barriers and five serial global-load
+// latencies per chunk: 86 k of a candidate's 530 k cycles.)  Leaves a barrier behind.
 template <int T>
 __device__ __forceinline__ void hess_dg_prepass_mfma(const KernParams& kp, int n, int npad, int q,
                                                      const lds_f64* xq, const lds_f64* pv, lds_f64* tab,
-                                                     size_t tabsz, lds_f64* Dg, lds_f64* wscratch,
+                                                     size_t tabsz, lds_f64* Dg, lds_f64* wscratch, size_t wsz,
                                                      const double* __restrict__ Xtrain,
                                                      const double* __restrict__ alpha,
-                                                     const double* __restrict__ Wrows) {
+                                                     const double* __restrict__ Wrows
+#ifdef OEI_HESS_TIMING
+                                                     , long long (&dt_)[4]
+#endif
+                                                     ) {
     constexpr int NW = T / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = kp.d, dl = (d + 1) | 1, dp = d + 1;
@@ -380,96 +388,107 @@ __device__ __forceinline__ void hess_dg_prepass_mfma(const KernParams& kp, int n
     const int li = lane & 15, kk = lane >> 4;
     const int ia = li / dp, r = li - ia * dp;
     const bool rowlive = ia < na;
-    const int per_pass = NW * na;
-    for (int a_lo = 0; a_lo < q; a_lo += per_pass) {
-        const int a_cnt = min(q - a_lo, per_pass);
-        int ch_max = (int)((tabsz - 2 * a_cnt) / (2 * a_cnt + dl));
-        ch_max = min(ch_max & ~3, 64);
-        int ch = 4, best = INT_MAX;
-        for (int c = 4; c <= ch_max; c += 4) {
-            const int chunks = (n + c - 1) / c, cost = chunks * (4 * ((a_cnt * c + T - 1) / T) + 1);
-            if (cost <= best) { best = cost; ch = c; }
+    const float rd = 1.0f / (float)d;
+#ifdef OEI_HESS_TIMING
+    long long tt_ = clock64();
+#define PRE_STAMP(i) do { const long long t2_ = clock64(); dt_[i] += t2_ - tt_; tt_ = t2_; } while (0)
+#else
+#define PRE_STAMP(i) do { } while (0)
+#endif
+    const bool xall = (size_t)n * dl <= tabsz;           // uniform
+    if (xall) {
+        for (int e = tid; e < n * d; e += T) {
+            const int k = (int)(((float)e + 0.5f) * rd), l = e - k * d;      // exact for e < 2^22 / d
+            tab[k * dl + l] = Xtrain[e];
         }
-        lds_f64* c1 = tab;                        // [a_cnt][ch+1]  coef * 2 var kappa'
-        lds_f64* c2 = c1 + a_cnt * (ch + 1);      // [a_cnt][ch+1]  coef * 4 var kappa''
-        lds_f64* Xc = c2 + a_cnt * (ch + 1);      // [ch][dl]
-        const int at = wave * na + ia;            // this lane's point within the pass
-        const bool live = rowlive && at < a_cnt;
-        const int ac = live ? at : 0;
+    }
+    __syncthreads();
+    PRE_STAMP(0);
+    int chs = 7;                                         // chunk length 2^chs <= 128 that fits the scratch
+    while (chs > 2 && (size_t)(2 * na * ((1 << chs) + 1) + (xall ? 0 : (1 << chs) * dl)) > wsz) --chs;
+    const int ch = 1 << chs, ch1 = ch + 1;
+    lds_f64* c1 = wscratch;                   // [na][ch+1]  coef * 2 var kappa'
+    lds_f64* c2 = c1 + na * ch1;              // [na][ch+1]  coef * 4 var kappa''
+    lds_f64* Xw = c2 + na * ch1;              // [ch][dl] (only without the shared copy)
+    for (int a_lo = wave * na; a_lo < q; a_lo += NW * na) {
+        const int a_cnt = min(q - a_lo, na);
+        const bool live = rowlive && ia < a_cnt;
+        const int ac = live ? ia : 0;
         const double xa = (live && r < d) ? xq[(a_lo + ac) * d + r] : 0.0;
         sens_double4 acc = (sens_double4){0.0, 0.0, 0.0, 0.0};
-        const int xk = tid / d, xl = tid - xk * d;              // staging element tid: training point, coordinate
-        const int ea = tid / ch, ek = tid - ea * ch;            // evaluation tid: point, training point
-        const bool xown = tid < ch * d, eown = tid < a_cnt * ch;
-        const double* wrow = Wrows + (size_t)(a_lo + (eown ? ea : 0)) * npad;
-        double nx = (xown && xk < n) ? Xtrain[(size_t)xk * d + xl] : 0.0;
-        double nal = (eown && ek < n) ? alpha[ek] : 0.0, nw = (eown && ek < n) ? wrow[ek] : 0.0;
         for (int c0 = 0; c0 < n; c0 += ch) {
-            __syncthreads();
-            if (xown) Xc[xk * dl + xl] = nx;
-            for (int e = tid + T; e < ch * d; e += T) {
-                const int k = e / d, l = e - k * d, kg = c0 + k;
-                Xc[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
-            }
-            const double cal = nal, cw = nw;
-            {
-                const int c1n = c0 + ch;
-                nx = (xown && c1n + xk < n) ? Xtrain[(size_t)(c1n + xk) * d + xl] : 0.0;
-                nal = (eown && c1n + ek < n) ? alpha[c1n + ek] : 0.0;
-                nw = (eown && c1n + ek < n) ? wrow[c1n + ek] : 0.0;
-            }
-            __syncthreads();
-            for (int e = tid; e < a_cnt * ch; e += T) {
-                const int aa = e / ch, k = e - aa * ch, kg = c0 + k, a = a_lo + aa;
-                double v1 = 0.0, v2 = 0.0;
-                if (kg < n) {
-                    double t = 0.0;
-                    for (int l = 0; l < d; ++l) {
-                        const double df = xq[a * d + l] - Xc[k * dl + l];
-                        t += df * df * kp.inv_ls2[l];
-                    }
-                    double k0, k1, k2;
-                    kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
-                    const double coef = (e == tid) ? pv[a] * cal - 2.0 * cw
-                                                   : pv[a] * alpha[kg] - 2.0 * Wrows[(size_t)a * npad + kg];
-                    v1 = coef * 2.0 * kp.variance * k1;
-                    v2 = coef * 4.0 * kp.variance * k2;
+            sens_sync<true>();
+            if (!xall) {
+                for (int e = lane; e < ch * d; e += 64) {
+                    const int k = (int)(((float)e + 0.5f) * rd), l = e - k * d, kg = c0 + k;
+                    Xw[k * dl + l] = (kg < n) ? Xtrain[(size_t)kg * d + l] : 0.0;
                 }
-                c1[aa * (ch + 1) + k] = v1;
-                c2[aa * (ch + 1) + k] = v2;
+                sens_sync<true>();
             }
-            __syncthreads();
-            if (wave * na < a_cnt) {
-                for (int s4 = 0; s4 < ch; s4 += 4) {
-                    const int k = s4 + kk;
-                    const double diff = xa - Xc[k * dl + (r < d ? r : 0)];
-                    const double cc = (r < d ? c2 : c1)[ac * (ch + 1) + k];
-                    const double av = live ? (r < d ? cc * diff : cc) : 0.0;
-                    const double bv = live ? (r < d ? diff : 1.0) : 0.0;
+            const lds_f64* Xc = xall ? tab + (size_t)c0 * dl : Xw;      // row k of the chunk at Xc + k dl
+#pragma unroll 4
+            for (int e = lane; e < a_cnt * ch; e += 64) {
+                const int aa = e >> chs, k = e & (ch - 1), kg = c0 + k, a = a_lo + aa;
+                const bool in = kg < n;
+                const int kgc = in ? kg : 0;
+                const double al = alpha[kgc], wv = Wrows[(size_t)a * npad + kgc];
+                double t = 0.0;
+                for (int l = 0; l < d; ++l) {
+                    const double df = xq[a * d + l] - Xc[(in ? k : 0) * dl + l];
+                    t += df * df * kp.inv_ls2[l];
+                }
+                double k0, k1, k2;
+                kappa_eval<2>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+                const double coef = pv[a] * al - 2.0 * wv;
+                c1[aa * ch1 + k] = in ? coef * 2.0 * kp.variance * k1 : 0.0;
+                c2[aa * ch1 + k] = in ? coef * 4.0 * kp.variance * k2 : 0.0;
+            }
+            sens_sync<true>();
+            PRE_STAMP(1);
+            const int kend = min(ch, (n - c0 + 3) & ~3);            // whole groups of four; entries past n are zeros
+            // four steps at a time: their eight LDS reads first, then the matrix instructions
+            // (one step at a time every instruction waited for its own reads: 350 cycles a step)
+            const lds_f64* crow = (r < d ? c2 : c1) + ac * ch1 + kk;
+            const lds_f64* xcol = Xc + (r < d ? r : 0);
+            for (int s4 = 0; s4 < kend; s4 += 16) {
+                double xv[4], cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = s4 + 4 * u + kk;
+                    const bool in = c0 + k < n && s4 + 4 * u < kend;
+                    xv[u] = xcol[(in ? k : 0) * dl];
+                    cv[u] = crow[in ? s4 + 4 * u : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = c0 + s4 + 4 * u + kk < n && s4 + 4 * u < kend;
+                    const double diff = xa - xv[u];
+                    const double av = (live && in) ? (r < d ? cv[u] * diff : cv[u]) : 0.0;
+                    const double bv = (live && in) ? (r < d ? diff : 1.0) : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
             }
+            PRE_STAMP(2);
         }
         // tile -> the wave's scratch (row-major 16 x 16), then the diagonal blocks -> Dg
+        sens_sync<true>();
 #pragma unroll
         for (int g = 0; g < 4; ++g) wscratch[(kk + 4 * g) * 16 + li] = acc[g];
         sens_sync<true>();
-        for (int e = lane; e < na * d * d; e += 64) {
+        for (int e = lane; e < a_cnt * d * d; e += 64) {
             const int ja = e / (d * d), rem = e - ja * d * d, l = rem / d, m2 = rem - l * d;
-            const int a = a_lo + wave * na + ja;
-            if (wave * na + ja < a_cnt) {
-                const int lo = min(l, m2), hi = max(l, m2);          // one triangle: exactly symmetric
-                double v = wscratch[(ja * dp + lo) * 16 + ja * dp + hi] * kp.inv_ls2[l] * kp.inv_ls2[m2];
-                if (l == m2) v += wscratch[(ja * dp + d) * 16 + ja * dp + d] * kp.inv_ls2[l];
-                Dg[(a * d + l) * d + m2] = v;
-            }
+            const int a = a_lo + ja;
+            const int lo = min(l, m2), hi = max(l, m2);          // one triangle: exactly symmetric
+            double v = wscratch[(ja * dp + lo) * 16 + ja * dp + hi] * kp.inv_ls2[l] * kp.inv_ls2[m2];
+            if (l == m2) v += wscratch[(ja * dp + d) * 16 + ja * dp + d] * kp.inv_ls2[l];
+            Dg[(a * d + l) * d + m2] = v;
         }
         sens_sync<true>();
     }
+    PRE_STAMP(3);
     __syncthreads();
 }
 
-// self-covariance part of Dg: 2 sum_{c != a} M11_ac Hs_ac
 template <int T, typename MP, typename TP, typename DP>
 __device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, const lds_f64* xq,
                                                 MP M11, TP k1s, TP k2s, DP Dg) {
@@ -892,10 +911,21 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         for (int e = tid; e < 5 * VL; e += T) rc[e] = sb[3 * ML + e];     // rc sq rp c t1 likewise
     }
     __syncthreads();
+#ifdef OEI_HESS_TIMING
+    const long long t_pre0 = clock64();
+    long long pre_cyc[4] = {0, 0, 0, 0};
+#endif
     if (d < 16)       // a point's d + 1 rows fit the 16-row tile
-        hess_dg_prepass_mfma<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, wbase, Xtrain, alpha, Wm + b * (size_t)q * npad);
+        hess_dg_prepass_mfma<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, wbase, hess_dirs_wave_doubles(q), Xtrain, alpha, Wm + b * (size_t)q * npad
+#ifdef OEI_HESS_TIMING
+                                , pre_cyc
+#endif
+                                );
     else
         hess_dg_prepass<T>(kp, n, npad, q, xq, pv, tab, hess_tab_doubles(q, d), Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+#ifdef OEI_HESS_TIMING
+    const long long t_pre1 = clock64();
+#endif
     build_tables<T>(kp, q, xq, Gb, RP, mu, tab, dmuT, k1s, k2s);
     const lds_f64* DS = tab;
     hess_dg_selfcov<T>(kp, q, xq, (const lds_f64*)M11, k1s, k2s, Dg);
@@ -923,6 +953,9 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         sens_sync<true>();
         for (int e = lane; e < ML; e += 64) L[e] = Xi[e];
     }
+#ifdef OEI_HESS_TIMING
+    const long long t_pre2 = clock64();
+#endif
     // Row (b,m) of the table becomes U^T v'_(b,m) (v'_j = dSigma_bj/dx_bm, j != b; half of it at
     // j = b), in place: it is both the direction's own input and what the contraction of every
     // other direction meets, so no direction forms dN = Y U^T.  On the matrix pipe: a wave takes 16
@@ -978,6 +1011,8 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     long long sens_cyc[12] = {};
     const long long t_dirs0 = clock64();
     sens_cyc[11] = t_dirs0 - t_kernel0;
+    sens_cyc[8] = t_pre1 - t_kernel0;
+    sens_cyc[9] = t_pre2 - t_pre1;
 #endif
     for (int al = wave + NW * slice; al < qd; al += NW * nslice) {
         const int a = al / d, l = al - a * d;
@@ -1007,7 +1042,11 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
     sens_cyc[10] = clock64() - t_dirs0;
     __syncthreads();
     if (b == 0 && slice == 0 && tid == 0)
+    {
         for (int i = 0; i < 12; ++i) Hb[i] = (double)sens_cyc[i];
+        for (int i = 0; i < 4; ++i) Hb[16 + i] = (double)pre_cyc[i];
+        Hb[20] = (double)(t_pre0 - t_kernel0);
+    }
 #endif
     // a solve that stopped at the Newton iteration limit (status 1) still gets its Hessian
     if (slice == 0 && tid == 0 && status) status[b] = sdp_status ? sdp_status[b] : 0;

@@ -13,9 +13,10 @@ X = torch.as_tensor(np.random.RandomState(1).uniform(-.5, .5, (2048, 20, 6)), de
 for _ in range(3):
     H, st = gp.hessian(X)
 torch.cuda.synchronize()
-c = H[0].flatten()[:12].cpu().numpy()
+c = H[0].flatten()[:24].cpu().numpy()
 names = ['ZS pass', 'M1 = ZS Rs^T, t2', 'rhs, two solves', 'rd, R^T dD R', 'Z pass', 'Y = U Z, t2', 'dc, w1, w2', 'dN mu, contraction']
 for n_, v in zip(names, c[:8]):
     print('%-24s %9.0f cycles (10 directions of wave 0)' % (n_, v))
 print('directions in all        %9.0f' % c[10])
-print('prologue                 %9.0f' % c[11])
+print('prologue                 %9.0f  (loads + diagonal-block pre-pass %.0f, tables + L^-1 %.0f, table transform %.0f)' % (c[11], c[8], c[9], c[11] - c[8] - c[9]))
+print('initial loads %.0f; pre-pass: staging of X %.0f, kernel derivatives %.0f, matrix instructions %.0f, tile to Dg %.0f' % (c[20], c[16], c[17], c[18], c[19]))
