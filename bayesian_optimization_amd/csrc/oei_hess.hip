@@ -774,7 +774,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
 // directions of a candidate are independent, and one wave per candidate leaves most of the chip
 // idle for the batch sizes a BO loop produces.
 //
-// state per candidate: U, R, L (q x LD each), then rc, sq, rp, c, t1 (VL each)
+// state per candidate: U, R, L^-1 (q x LD each), then rc, sq, rp, c, t1 (VL each)
 __host__ __device__ inline size_t hess_state_doubles(int q) {
     return (size_t)3 * q * sdp_ld(q) + (size_t)5 * sdp_vlen(q);
 }
@@ -824,6 +824,32 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_hess_prep(KernParams kp
     if (!st && sens_prepare<T, Q>(w, mu, sv)) st = 2;
     if (tid == 0) stflag[b] = st;
     if (st) return;
+    // L -> L^-1 in place, as a full matrix (zeros above the diagonal): the directions solve with two
+    // matrix-vector products.  Lane j forms column j by forward substitution, x_i = -(sum_{k<i}
+    // L_ik x_k) / L_ii with x_k = 0 for k < j and x_j = 1 / L_jj; the entries of L are broadcast reads.
+    {
+        double x[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            x[i] = 0.0;
+            if (i < q) {
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) {
+                    const double l = w.H[i * LD + k];
+                    if (k & 1) acc1 = fma(l, x[k], acc1); else acc0 = fma(l, x[k], acc0);
+                }
+                const double rci = w.rc[i];
+                x[i] = (i == tid) ? rci : -(acc0 + acc1) * rci;
+            }
+        }
+        __syncthreads();
+        if (tid < q) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) if (i < q) w.H[i * LD + tid] = (i >= tid) ? x[i] : 0.0;
+        }
+        __syncthreads();
+    }
     double* sb = state + b * hess_state_doubles(q);
     const int ML = q * LD;
     for (int e = tid; e < ML; e += T) {
@@ -935,24 +961,8 @@ __global__ __launch_bounds__(T) void k_hess_dirs(KernParams kp, int n, int npad,
         phiS[a * LD + c] = -0.5 * sdp_rcp(sa * sc * (sa + sc));
         phiD[a * LD + c] = 0.5 * sdp_rcp(sa + sc);
     }
-    // L -> L^-1 in place (through the first wave's scratch): the directions solve with two
-    // matrix-vector products.  Lane j forms column j: X_jj = 1 / L_jj, X_ij = -(sum_{j<=k<i} L_ik X_kj) / L_ii.
-    if (wave == 0) {
-        lds_f64* Xi = wbase;
-        for (int e = lane; e < ML; e += 64) Xi[e] = 0.0;
-        sens_sync<true>();
-        if (lane < q) {
-            const int j = lane;
-            Xi[j * LD + j] = rc[j];
-            for (int i = j + 1; i < q; ++i) {
-                double acc = 0.0;
-                for (int k = j; k < i; ++k) acc = fma(L[i * LD + k], Xi[k * LD + j], acc);
-                Xi[i * LD + j] = -acc * rc[i];
-            }
-        }
-        sens_sync<true>();
-        for (int e = lane; e < ML; e += 64) L[e] = Xi[e];
-    }
+    // (the state's third matrix is L^-1, full with zeros above the diagonal: the preparation kernel
+    // inverts the factor in registers, and the directions solve with two matrix-vector products)
 #ifdef OEI_HESS_TIMING
     const long long t_pre2 = clock64();
 #endif
