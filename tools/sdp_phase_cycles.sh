@@ -6,7 +6,7 @@ set -e
 SRC=${3:-bayesian_optimization_amd/csrc}
 D=$(mktemp -d)
 for f in oei_model oei_gemm oei_sdp oei_acq oei_hess oei_fit oei_lbfgs oei_newton oei_multistart; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 --offload-arch=gfx950 -DOEI_SDP_TIMING -c $SRC/$f.hip -o $D/$f.o 2>/dev/null &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -mllvm -pragma-unroll-threshold=1000000 -mllvm -amdgpu-mfma-vgpr-form --offload-arch=gfx950 -DOEI_SDP_TIMING -c $SRC/$f.hip -o $D/$f.o 2>/dev/null &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboei_timing.so $D/*.o
