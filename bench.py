@@ -7,9 +7,9 @@ One step = one pass of the hot path over one batch of synthetic candidate batche
 in HBM: value + gradient of B candidates (q=20, d=6) under the n=310 hart6 GP, the local arg-min
 and, for N > 1, the all-gather of the (value, index, X) record that picks the best start.  Work per
 GPU is fixed (weak scaling).  Rank 0 prints ONE JSON line.  Order inside a rank: model, Hessian
-throughput leg (untimed; heavy GPU work that also leaves the clocks up), W warm-up steps, barrier,
-K timed steps, barrier; then the profiled calls for the roofline, the callers' legs and the CPU
-baseline.
+throughput leg and the profiled calls for the roofline (untimed; GPU work that also leaves clocks,
+caches and allocator as a running loop has them), W warm-up steps, barrier, K timed steps, barrier;
+then the callers' legs and the CPU baseline.
 
 With --gpus N > 1 and no WORLD_SIZE in the environment this process only launches: it starts N
 ranks of itself (one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1),
@@ -246,6 +246,27 @@ def main():
         torch.cuda.synchronize()
         hess_timing = (hb, hreps, (time.perf_counter() - th) / hreps, int((hst != 0).sum().item()))
 
+    # ---- roofline of the dominant kernel, measured live with HIP events on its stream: profiled
+    # calls of the timed workload on one stream, ahead of the timed steps (they also leave caches,
+    # allocator and clocks in the state of a running loop) ----
+    prof_timing = None
+    if not cpu_only:
+        gp.set_profiling(True)
+        for _ in range(30):
+            gp.value_grad(X_local, want_flags=False)
+        stage = np.zeros(5)
+        kernel_ms = 0.0
+        reps = 10
+        for i in range(2 * reps):
+            gp.value_grad(X_local, want_flags=False)
+            if i >= reps:
+                stage += np.array(gp.stage_times_ms())
+                kernel_ms += gp.solver_kernel_ms()
+        stage /= reps
+        kernel_ms /= reps
+        gp.set_profiling(False)
+        prof_timing = (stage, kernel_ms, reps)
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -276,23 +297,7 @@ def main():
         evals_per_s = total * args.steps / dt
         roofline = hessian = cpu = callers = None
         if not cpu_only:
-            # ---- roofline of the dominant kernel, measured live with HIP events on its stream ----
-            gp.set_profiling(True)
-            # (the host work above let the GPU idle and its clocks drop: warm calls first, then
-            # profiled calls back to back, the first ten of them discarded)
-            for _ in range(30):
-                gp.value_grad(X_local, want_flags=False)
-            stage = np.zeros(5)
-            kernel_ms = 0.0
-            reps = 10
-            for i in range(2 * reps):
-                gp.value_grad(X_local, want_flags=False)
-                if i >= reps:
-                    stage += np.array(gp.stage_times_ms())
-                    kernel_ms += gp.solver_kernel_ms()
-            stage /= reps
-            kernel_ms /= reps
-            gp.set_profiling(False)
+            stage, kernel_ms, reps = prof_timing
             names = ['gram', 'gemm_cross', 'moments_sdp', 'gemm_back', 'gradient']
             omg = gp.omega(X_local)
             _, _, _, st2, iters = sdp_batched(omg, gp.fmin, want_Y=False)
