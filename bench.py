@@ -76,13 +76,15 @@ def hessian_flops_model(q, d, n, npad, sdp_flops, executed=False):
                 the vector passes and the two triangular solves, and the contraction of the
                 direction's row with every dOmega_(b,m): q d (2 q + 30)
     Useful work only: the rows that carry data.  `executed` counts what the kernels multiply
-    instead -- blocks padded to a multiple of 64 rows, whole 64 x 64 tiles of the block Gram matrix."""
+    instead -- blocks padded to a multiple of 16 rows, whole 64 x 64 tiles (or 16-row strips) of the block Gram matrix."""
     rows = q * (d + 1) + 1
     nt = npad // 64
     tri = 64 * 64 * nt * (nt + 1)                      # per row: column tile j takes 64 * 64 (j + 1) multiply-adds
     if executed:
-        RP = -(-rows // 64) * 64
-        front = RP * tri + (RP // 64) * (RP // 64 + 1) // 2 * 2 * 64 * 64 * npad
+        RP = -(-rows // 16) * 16                       # blocks are packed to a multiple of 16 rows
+        nfull, rem = RP // 64, RP % 64
+        rem_exec = 0 if rem == 0 else (16 if rem <= 16 else 64)     # a last tile of 16 rows runs as a strip
+        front = RP * tri + (nfull * (nfull + 1) // 2 * 64 * 64 + rem_exec * 64 * (nfull + 1)) * 2 * npad
     else:
         front = rows * tri + rows * (rows + 1) * npad  # Gram: rows (rows + 1) / 2 sums of npad multiply-adds
     solve = sdp_flops + q * tri
@@ -350,7 +352,7 @@ def main():
                                         'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                         'frac': hfl * hb / th / 1e12 / FP64_PEAK_TFLOPS,
                                         'note': 'whole call (8 launches), wall clock over %d calls; flops of the rows that '
-                                                'carry data (the executed count includes the padding of a block to whole tiles)' % hreps}}
+                                                'carry data (the executed count includes the padding of a block to 16 rows and whole tiles of its Gram matrix)' % hreps}}
             if not args.no_hessian and world == 1:
                 # the callers of the path, outside the timed region: 2048 multistart descents
                 # through the device optimiser, and a hyper-parameter fit with 20 restarts
