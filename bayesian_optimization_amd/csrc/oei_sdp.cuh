@@ -47,7 +47,9 @@
 #endif
 #define SDP_MAX_NEWTON 60
 #define SDP_MAX_SWEEPS 30
+#ifndef SDP_JACOBI_TOL
 #define SDP_JACOBI_TOL 1e-15
+#endif
 // Stop after a full Newton step of relative size below this.  The iteration converges
 // quadratically with a constant near one (relative steps 4e-2, 1e-3, 1e-6, 5e-13 on the
 // benchmark inputs), so the point reached is within about 1e-11 of the optimum; a tolerance of
@@ -58,7 +60,9 @@
 #define SDP_JACOBI_FINAL 1e-7
 #endif
 // evaluations that only steer the Newton iteration (every one but the last) stop earlier
+#ifndef SDP_JACOBI_TOL_LOOSE
 #define SDP_JACOBI_TOL_LOOSE 1e-11
+#endif
 #ifndef SDP_JACOBI_FINAL_LOOSE
 #define SDP_JACOBI_FINAL_LOOSE 1e-5
 #endif
