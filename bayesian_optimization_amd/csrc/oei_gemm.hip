@@ -309,23 +309,44 @@ __device__ __forceinline__ void gemm_tile_nt_tall(const double* __restrict__ Ag0
     gemm_tile_store<2>(Cg, ldc, acc);
 }
 
+// Column tiles of a triangular product differ in their K range (tile j of nt: j + 1 units for a
+// lower operand, nt - j for an upper one).  A workgroup takes a chain of one or two tiles of its row
+// block whose units add up to nt -- the longest tile alone, then the second longest with the
+// shortest, and so on -- so that every workgroup does the same work and there are (nt + 1) / 2
+// starts per row block instead of nt.
+__device__ __forceinline__ int gemm_chain_tiles(int chain, int nt, int lower, int (&tiles)[2]) {
+    // ranks by length: rank 0 is the longest tile
+    auto tile_of_rank = [&](int r) { return lower ? nt - 1 - r : r; };
+    if (chain == 0) { tiles[0] = tile_of_rank(0); return 1; }
+    const int ra = chain, rb = nt - chain;           // ranks ra (long) and rb (short), ra <= rb
+    tiles[0] = tile_of_rank(ra);
+    if (rb == ra) return 1;
+    tiles[1] = tile_of_rank(rb);
+    return 2;
+}
+
 __global__ __launch_bounds__(256) void k_gemm_nt_tall(const double* __restrict__ A,
                                                       const double* __restrict__ Bm,
                                                       double* __restrict__ C, int npad, int lower,
                                                       unsigned nrb) {
     __shared__ __attribute__((aligned(16))) double As[2 * GM_BM2 * GM_LDS];
     __shared__ __attribute__((aligned(16))) double Bs[2 * GM_BN * GM_LDS];
-    // same workgroup order as k_gemm_nt: the column tiles of one row panel share an XCD (one L2)
-    const int nt = npad / GM_BN;
+    // same workgroup order as k_gemm_nt: the chains of one row panel share an XCD (one L2)
+    const int nt = npad / GM_BN, nch = nt / 2 + 1;
     const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const size_t rb = (size_t)(slot / nt) * 8 + xcd;
+    const size_t rb = (size_t)(slot / nch) * 8 + xcd;
     if (rb >= nrb) return;
-    const int j0 = (int)(slot % nt) * GM_BN;
+    int tiles[2];
+    const int ntile = gemm_chain_tiles((int)(slot % nch), nt, lower, tiles);
     const size_t r0 = rb * GM_BM2;
-    const int kbeg = lower ? 0 : j0;
-    const int kend = lower ? (j0 + GM_BN) : npad;
-    if (lower) gemm_tile_nt_tall<1>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
-    else gemm_tile_nt_tall<2>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+    for (int i = 0; i < ntile; ++i) {
+        const int j0 = tiles[i] * GM_BN;
+        const int kbeg = lower ? 0 : j0;
+        const int kend = lower ? (j0 + GM_BN) : npad;
+        if (i) __syncthreads();                      // the previous tile's fragment reads are done
+        if (lower) gemm_tile_nt_tall<1>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+        else gemm_tile_nt_tall<2>(A + r0 * npad, Bm + (size_t)j0 * npad, C + r0 * npad + j0, npad, npad, kbeg, kend, As, Bs);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_gemm_nt(const double* __restrict__ A,
@@ -358,7 +379,7 @@ int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows
     const unsigned nt = (unsigned)(npad / GM_BN);
     if (rows_pad % GM_BM2 == 0) {
         const unsigned nrb = (unsigned)(rows_pad / GM_BM2);
-        dim3 grid(((nrb + 7) / 8) * 8 * nt);
+        dim3 grid(((nrb + 7) / 8) * 8 * (nt / 2 + 1));
         hipLaunchKernelGGL(k_gemm_nt_tall, grid, dim3(256), 0, st, A, Bm, C, npad, lower, nrb);
     } else {
         const unsigned nrb = (unsigned)(rows_pad / GM_BM);
@@ -401,17 +422,22 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void k_gemm_grad(const double
     __shared__ __attribute__((aligned(16))) double As[(DBUF ? 2 : 1) * NH * GM_BM * GM_LDS];
     __shared__ __attribute__((aligned(16))) double Bs[(DBUF ? 2 : 1) * GM_BN * GM_LDS];
     __shared__ double Xs[64 * (DPM + 1)];
-    // one column tile per workgroup; the tiles of one row block of Z get consecutive slots of
-    // the same XCD (as in k_gemm_nt), so they run together and share the block through that L2
-    const int nt = npad / GM_BN, dp = d + 1;
+    // a balanced chain of one or two column tiles per workgroup (gemm_chain_tiles); the chains of
+    // one row block of Z get consecutive slots of the same XCD (as in k_gemm_nt), so they run
+    // together and share the block through that L2
+    const int nt = npad / GM_BN, nch = nt / 2 + 1, dp = d + 1;
     const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const size_t rb = (size_t)(slot / nt) * 8 + xcd;
+    const size_t rb = (size_t)(slot / nch) * 8 + xcd;
     if (rb >= nrb) return;
-    const unsigned split = slot % nt;
+    int tiles[2];
+    const int ntile = gemm_chain_tiles((int)(slot % nch), nt, 0, tiles);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kg = lane >> 4;
     const size_t r0 = (size_t)rb * (NH * GM_BM);
+  for (int it = 0; it < ntile; ++it) {
+    const unsigned split = (unsigned)tiles[it];
     const int j0 = (int)split * GM_BN;
+    if (it) __syncthreads();                         // the previous tile's readers of Xs and the panels are done
     for (int e = tid; e < 64 * dp; e += 256) {
         const int k = e / dp, l = e - k * dp;
         Xs[k * (DPM + 1) + l] = (l < d) ? Xtrain[(size_t)(j0 + k) * d + l] : 1.0;
@@ -453,6 +479,7 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void k_gemm_grad(const double
             }
         }
     }
+  }
 }
 
 // Gpart [npad / 64][nrows][d+1]; returns OEI_ERR_ARG when d + 1 exceeds the register budget of the
@@ -465,7 +492,7 @@ int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, 
     // The instance for d + 1 <= 8 keeps X in a smaller LDS array: four workgroups per compute unit
     // instead of three, 0.210 against 0.226 ms.)
     const unsigned nrb = (unsigned)(rows_pad / GM_BM);
-    dim3 grid(((nrb + 7) / 8) * 8 * nt);
+    dim3 grid(((nrb + 7) / 8) * 8 * (nt / 2 + 1));
     if (m->d + 1 <= 8)
         hipLaunchKernelGGL((k_gemm_grad<8, 1>), grid, dim3(256), 0, st, Z, m->LinvT, K1, m->alpha, m->X, pvec, Gpart, m->npad, m->d, nrb, nrows);
     else
