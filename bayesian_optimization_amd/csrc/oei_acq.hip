@@ -537,8 +537,13 @@ __global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nr
     lds_f64* M11 = xq + q * d;                // [q][q]
     lds_f64* Gs = M11 + q * q;                // [q][q]     2 var kappa'(t_ab)
     lds_f64* Gl = Gs + q * q;                 // [q][d+1]
+    lds_f64* xr = Gl + q * dp;                // [q][d]     coordinates on the grid of the duplicate test
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int e = tid; e < q * d; e += T) xq[e] = Xq[(size_t)b * q * d + e];
+    for (int e = tid; e < q * d; e += T) {
+        const double x = Xq[(size_t)b * q * d + e];
+        xq[e] = x;
+        xr[e] = rint(x / kp.ls[e % d] * 100.0);          // once per coordinate, not twice per pair
+    }
     for (int e = tid; e < q * q; e += T) M11[e] = M11_in[(size_t)b * q * q + e];
     for (int e = tid; e < q * dp; e += T) {
         double acc = 0.0;
@@ -547,18 +552,21 @@ __global__ __launch_bounds__(64) void k_grad_fin(KernParams kp, int q, size_t nr
     }
     __syncthreads();
     int flag = 0;
-    for (int e = tid; e < q * q; e += T) {
-        const int a = e / q, bb = e - a * q;
+    for (int e = tid; e < q * (q + 1) / 2; e += T) {         // pairs a >= bb: the factor is symmetric
+        int a, bb;
+        sdp_tri_index(e, a, bb);
         double t = 0.0;
         bool same = true;
         for (int l = 0; l < d; ++l) {
             const double df = xq[a * d + l] - xq[bb * d + l];
             t += df * df * kp.inv_ls2[l];
-            same = same && (rint(xq[a * d + l] / kp.ls[l] * 100.0) == rint(xq[bb * d + l] / kp.ls[l] * 100.0));
+            same = same && (xr[a * d + l] == xr[bb * d + l]);
         }
         double k0, k1, k2;
         kappa_eval<1>(kp.kind, kp.floor_mode, t, k0, k1, k2);
-        Gs[e] = (a == bb) ? 0.0 : 2.0 * kp.variance * k1;
+        const double gv = (a == bb) ? 0.0 : 2.0 * kp.variance * k1;
+        Gs[a * q + bb] = gv;
+        Gs[bb * q + a] = gv;
         if (a != bb && same) flag = 1;
     }
     __syncthreads();
@@ -825,7 +833,7 @@ static int value_grad_run(oei_model* m, int B, int q, const double* X, double* v
         rc = oei_launch_gemm_grad(m, ws0, ws2, p_buf, Gpart, rows, rows_pad, st);
         if (rc) return rc;
         if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
-        const size_t ldsf = ((size_t)q * d + 2 * (size_t)q * q + (size_t)q * (d + 1)) * sizeof(double);
+        const size_t ldsf = ((size_t)2 * q * d + 2 * (size_t)q * q + (size_t)q * (d + 1)) * sizeof(double);
         if ((rc = set_lds(k_grad_fin, ldsf))) return rc;
         hipLaunchKernelGGL(k_grad_fin, dim3(B), dim3(64), ldsf, st, m->kp, q, rows, m->npad / 64, X, Gpart, M11_buf, grad, flags);
     } else {
