@@ -239,7 +239,7 @@ def main():
     if not cpu_only and not args.no_hessian:
         hb = min(B, 2048)
         hreps = 20
-        for _ in range(5):                      # buffers, then clocks
+        for _ in range(15):                     # buffers, then clocks (this leg runs first, after the idle set-up)
             gp.hessian(X_local[:hb])
         torch.cuda.synchronize()
         th = time.perf_counter()
