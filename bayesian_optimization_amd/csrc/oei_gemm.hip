@@ -25,7 +25,12 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // once per block; stores are coalesced along k.
 #define GR_ROWS 32
 
-template <bool WITH_K1>
+// DM > 0: instance for d <= DM.  The thread's training point sits in registers for its GR_ROWS / 4
+// rows, the query rows are staged with a stride of DM (zero-padded, with zero weights behind d),
+// the loop over the coordinates is unrolled, and the per-coordinate closeness test of the
+// duplicate flag only runs behind its necessary condition t < d 1e-4.  The kernel is bound by
+// these vector instructions (with its stores removed it runs 0.110 instead of 0.124 ms).
+template <bool WITH_K1, int DM>
 __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __restrict__ Xtrain,
                                               int n, int npad, const double* __restrict__ Xq,
                                               size_t rows, double* __restrict__ out,
@@ -35,10 +40,59 @@ __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __res
     OEI_LDS_POISON(sm);
     const int d = kp.d;
     double* Xs = sm;                 // [64][d]
-    double* Qs = sm + 64 * d;        // [GR_ROWS][d]
+    double* Qs = sm + 64 * d;        // [GR_ROWS][d]  (DM > 0: [GR_ROWS][DM])
     const int tid = threadIdx.x;
     const int k0 = blockIdx.y * 64;
     const size_t r0 = (size_t)blockIdx.x * GR_ROWS;
+    if constexpr (DM > 0) {
+        for (int i = tid; i < 64 * d; i += 256) {
+            int k = k0 + i / d;
+            Xs[i] = (k < n) ? Xtrain[(size_t)k * d + (i % d)] : 0.0;
+        }
+        for (int i = tid; i < GR_ROWS * DM; i += 256) {
+            const size_t r = r0 + i / DM;
+            const int l = i % DM;
+            Qs[i] = (r < rows && l < d) ? Xq[r * d + l] : 0.0;
+        }
+        __syncthreads();
+        const int kk = tid & 63;
+        const int k = k0 + kk;
+        double xk[DM], w2[DM];
+#pragma unroll
+        for (int l = 0; l < DM; ++l) {
+            xk[l] = (l < d) ? Xs[kk * d + l] : 0.0;
+            w2[l] = (l < d) ? kp.inv_ls2[l] : 0.0;
+        }
+        const double tclose = 1e-4 * d;
+        for (int rr = tid >> 6; rr < GR_ROWS; rr += 4) {
+            const size_t r = r0 + rr;
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int l = 0; l < DM; l += 2) {
+                const double d0 = Qs[rr * DM + l] - xk[l];
+                t0 = fma(d0 * d0, w2[l], t0);
+                if (l + 1 < DM) {
+                    const double d1 = Qs[rr * DM + l + 1] - xk[l + 1];
+                    t1 = fma(d1 * d1, w2[l + 1], t1);
+                }
+            }
+            const double t = t0 + t1;
+            double k0v, k1v, k2v;
+            kappa_eval<WITH_K1 ? 1 : 0>(kp.kind, kp.floor_mode, t, k0v, k1v, k2v);
+            const bool in = (r < rows) && (k < n);
+            out[r * npad + k] = in ? kp.variance * k0v : 0.0;
+            if (WITH_K1) {
+                out1[r * npad + k] = in ? 2.0 * kp.variance * k1v : 0.0;
+                if (in && flags && t < tclose) {             // every |df_l| / ls_l < 1e-2 implies t < d 1e-4
+                    bool close = true;
+                    for (int l = 0; l < d; ++l)
+                        close = close && (fabs((Qs[rr * DM + l] - xk[l]) * kp.inv_ls[l]) < 1e-2);
+                    if (close) flags[r / q] = 1;             // every writer stores the same value
+                }
+            }
+        }
+        return;
+    }
     for (int i = tid; i < 64 * d; i += 256) {
         int k = k0 + i / d;
         Xs[i] = (k < n) ? Xtrain[(size_t)k * d + (i % d)] : 0.0;
@@ -73,11 +127,19 @@ __global__ __launch_bounds__(256) void k_gram(KernParams kp, const double* __res
 int oei_launch_gram(const oei_model* m, const double* Xq, size_t rows, size_t rows_pad,
                     double* Ks, double* K1, int q, int* flags, hipStream_t st) {
     dim3 grid((unsigned)(rows_pad / GR_ROWS), m->npad / 64);
-    size_t lds = (size_t)(64 + GR_ROWS) * m->d * sizeof(double);
-    if (K1)
-        hipLaunchKernelGGL(k_gram<true>, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, K1, q, flags);
-    else
-        hipLaunchKernelGGL(k_gram<false>, grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, (double*)nullptr, 1, (int*)nullptr);
+    if (m->d <= 8) {
+        const size_t lds = ((size_t)64 * m->d + (size_t)GR_ROWS * 8) * sizeof(double);
+        if (K1)
+            hipLaunchKernelGGL((k_gram<true, 8>), grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, K1, q, flags);
+        else
+            hipLaunchKernelGGL((k_gram<false, 8>), grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, (double*)nullptr, 1, (int*)nullptr);
+    } else {
+        const size_t lds = (size_t)(64 + GR_ROWS) * m->d * sizeof(double);
+        if (K1)
+            hipLaunchKernelGGL((k_gram<true, 0>), grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, K1, q, flags);
+        else
+            hipLaunchKernelGGL((k_gram<false, 0>), grid, dim3(256), lds, st, m->kp, m->X, m->n, m->npad, Xq, rows, Ks, (double*)nullptr, 1, (int*)nullptr);
+    }
     OEI_HIP_CHECK(hipGetLastError());
     return OEI_OK;
 }

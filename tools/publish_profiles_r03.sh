@@ -30,7 +30,7 @@ import json
 h = json.load(open('profiles/r03_pmc_hbm.json'))
 p = 'profiles/pmc_traffic.json'
 d = json.load(open(p))
-step = {k: h[k]['hbm_bytes_per_launch'] for k in ('k_gram<true>', 'k_gemm_nt_tall', 'k_stage2<64, 20>', 'k_gemm_grad<8, 1>', 'k_grad_fin', 'k_best_record')}
+step = {k: h[k]['hbm_bytes_per_launch'] for k in ('k_gram<true, 8>', 'k_gemm_nt_tall', 'k_stage2<64, 20>', 'k_gemm_grad<8, 1>', 'k_grad_fin', 'k_best_record')}
 d['moments_sdp_hbm_bytes_per_launch'] = step['k_stage2<64, 20>']
 d['step_hbm_bytes_by_kernel'] = step
 d['step_hbm_bytes'] = sum(step.values())
