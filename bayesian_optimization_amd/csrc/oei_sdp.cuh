@@ -346,6 +346,9 @@ __device__ int sdp_jacobi_cols(lds_f64* Gc, int q, int LD, double tol2, double f
     return sweep;
 }
 
+template <int NR>
+__device__ int sdp_jacobi_rows4(lds_f64* Gc, int q, int LD, double tol2, double fin2, lds_f64* red);
+
 // Evaluate g, grad g and the eigen-state at pt.  Needs w.S, w.rc from sdp_factor_wide.  With
 // SDP_EVAL_WARM the previous state (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in
 // w.sv) seeds this one: G <- G V_prev.  Leaves U in w.X and the vectors sq, sv, rp, s, rs, ip,
@@ -427,7 +430,13 @@ __device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps,
         const bool loose = (mode & SDP_EVAL_LOOSE) != 0;
         const double tol = loose ? SDP_JACOBI_TOL_LOOSE : SDP_JACOBI_TOL;
         const double fin = (mode & SDP_EVAL_FIRST) ? SDP_JACOBI_FINAL_FIRST : loose ? SDP_JACOBI_FINAL_LOOSE : SDP_JACOBI_FINAL;
-        sweeps += sdp_jacobi_cols<T>(Gc, q, LD, tol * tol, fin * fin);
+        if constexpr (T == 256) {
+            // columns in registers, w.X (free until U is written below) as the reduction buffer
+            sweeps += loose ? sdp_jacobi_rows4<1>(Gc, q, LD, tol * tol, fin * fin, w.X)
+                            : sdp_jacobi_rows4<2>(Gc, q, LD, tol * tol, fin * fin, w.X);
+        } else {
+            sweeps += sdp_jacobi_cols<T>(Gc, q, LD, tol * tol, fin * fin);
+        }
     }
     SDP_TOC(1, t_jac);
     SDP_TIC(t_rest);
@@ -705,6 +714,144 @@ __device__ int sdp_jacobi_oe(double (&gt)[Q / 4], double (&gb)[Q / 4], double to
         }
         if (!__any(rotated)) { ++sweep; break; }
     }
+    return sweep;
+}
+
+// The same iteration for the 256-thread path (32 < q <= 64): the columns stay in registers here too.
+// Wave w holds the rows 16 w .. 16 w + 15 of every column: lane (part, kpos) = (lane >> 5, lane & 31)
+// the rows 16 w + 8 part .. + 7 of the columns at positions 2 kpos and 2 kpos + 1 of a linear array
+// of 2 K columns (K = ceil(q / 2) positions; columns and rows past q are zeros).  Odd-even
+// transposition as in sdp_jacobi_oe, the travelling column moving one lane with whole-wave DPP
+// shifts (wave_shl:1 / wave_shr:1; lane 32 is position 0 of the second row group and keeps its
+// own column).  A pair's dot product is summed over a lane's 8 rows, over the two row groups of
+// the wave (v_permlane32_swap) and over the four waves through LDS (`red`, 512 doubles: two
+// buffers in turn, one barrier per round) in one fixed order, so every wave takes the same
+// rotation decision with the same parameters.  Against the version with the columns in LDS
+// (sdp_jacobi_cols: every round reads and writes the whole matrix, 64 KB per workgroup) the LDS
+// traffic of a round is 1.5 KB.  In: column j at Gc[j * LD + r]; out: the same layout, columns in
+// the order the array ends in (an unordered set to the caller).  Returns the sweeps.
+template <int NR>
+__device__ int sdp_jacobi_rows4(lds_f64* Gc, int q, int LD, double tol2, double fin2, lds_f64* red) {
+    constexpr int RP = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kpos = lane & 31, part = lane >> 5;
+    const int K = (q + 1) >> 1;
+    const bool last = kpos == K - 1, first = kpos == 0;
+    const int row0 = 16 * wave + 8 * part;
+    double gt[RP], gb[RP];
+    {
+        const int ct = 2 * kpos, cb = 2 * kpos + 1;
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int r = row0 + i;
+            const bool rin = r < q;
+            const double xt = Gc[(ct < q ? ct : 0) * LD + (rin ? r : 0)], xb = Gc[(cb < q ? cb : 0) * LD + (rin ? r : 0)];
+            gt[i] = (rin && ct < q) ? xt : 0.0;
+            gb[i] = (rin && cb < q) ? xb : 0.0;
+        }
+    }
+    int flip = 0;
+    // sums of two per-lane partial values over all 64 rows of the lane's position, same bits everywhere
+    auto colsum2 = [&](double& v0, double& v1) {
+        const unsigned l0 = __double2loint(v0), h0 = __double2hiint(v0), l1 = __double2loint(v1), h1 = __double2hiint(v1);
+        const auto a = __builtin_amdgcn_permlane32_swap(l0, l0, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(h0, h0, false, false);
+        const auto c = __builtin_amdgcn_permlane32_swap(l1, l1, false, false);
+        const auto d = __builtin_amdgcn_permlane32_swap(h1, h1, false, false);
+        const double x0 = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+        const double x1 = __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+        lds_f64* rb = red + flip * 256;
+        flip ^= 1;
+        if (part == 0) { rb[wave * 32 + kpos] = x0; rb[128 + wave * 32 + kpos] = x1; }
+        __syncthreads();
+        v0 = (rb[kpos] + rb[32 + kpos]) + (rb[64 + kpos] + rb[96 + kpos]);
+        v1 = (rb[128 + kpos] + rb[160 + kpos]) + (rb[192 + kpos] + rb[224 + kpos]);
+    };
+    auto colsum = [&](double v) -> double {
+        const unsigned l0 = __double2loint(v), h0 = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(l0, l0, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(h0, h0, false, false);
+        const double x0 = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+        lds_f64* rb = red + flip * 256;
+        flip ^= 1;
+        if (part == 0) rb[wave * 32 + kpos] = x0;
+        __syncthreads();
+        return (rb[kpos] + rb[32 + kpos]) + (rb[64 + kpos] + rb[96 + kpos]);
+    };
+    int sweep = 0;
+    for (; sweep < SDP_MAX_SWEEPS; ++sweep) {
+        bool rotated = false;
+        double nt = 0.0, nb = 0.0;
+#pragma unroll
+        for (int i = 0; i < RP; ++i) { nt = fma(gt[i], gt[i], nt); nb = fma(gb[i], gb[i], nb); }
+        colsum2(nt, nb);                                  // squared norms of top and bottom
+        for (int r = 0; r < K; ++r) {
+            {   // even round: (top, bottom) of this lane; the rotated columns change places
+                double dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < RP; ++i) dot = fma(gt[i], gb[i], dot);
+                double c, sn;
+                rotated |= sdp_pair_rotation<NR>(colsum(dot), nt, nb, tol2, fin2, c, sn);
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const double l = gt[i], rr = gb[i];
+                    gt[i] = sn * l + c * rr;
+                    gb[i] = c * l - sn * rr;
+                }
+                const double t = nt; nt = nb; nb = t;
+            }
+            {   // odd round: (bottom of this lane, top of the next lane); the last position rests
+                double vis[RP];
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const double v = sdp_dpp_move<0x130, true>(0.0, gt[i]);          // wave_shl:1
+                    vis[i] = last ? 0.0 : v;
+                }
+                double nv = sdp_dpp_move<0x130, true>(0.0, nt);
+                nv = last ? 0.0 : nv;
+                double dot = 0.0;
+#pragma unroll
+                for (int i = 0; i < RP; ++i) dot = fma(gb[i], vis[i], dot);
+                double c, sn;
+                rotated |= sdp_pair_rotation<NR>(colsum(dot), nb, nv, tol2, fin2, c, sn) && !last;
+                // the last position has no visitor (a zero column): a quarter turn plus the exchange
+                // leaves its bottom column where it is and sends the zero column on
+                const double nb_rot = nb, nv_rot = nv;
+                if (last) { c = 0.0; sn = 1.0; }
+                nb = last ? nb_rot : nv_rot;
+                const double nsend = last ? nv_rot : nb_rot;
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const double l = gb[i], rr = vis[i];
+                    gb[i] = sn * l + c * rr;
+                    vis[i] = c * l - sn * rr;
+                }
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const double m = sdp_dpp_move<0x138, false>(gt[i], vis[i]);      // wave_shr:1
+                    gt[i] = first ? gt[i] : m;           // position 0 (lanes 0 and 32) keeps its top
+                }
+                const double mn = sdp_dpp_move<0x138, false>(nt, nsend);
+                nt = first ? nt : mn;
+            }
+        }
+        if (!__any(rotated)) { ++sweep; break; }
+    }
+    // where the columns are now: the array is reversed after an odd number of sweeps
+    const bool rev = (sweep & 1) != 0;
+    const int ot = rev ? 2 * K - 1 - 2 * kpos : 2 * kpos, ob = rev ? 2 * K - 2 - 2 * kpos : 2 * kpos + 1;
+    __syncthreads();
+    if (kpos < K) {
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int r = row0 + i;
+            if (r < q) {
+                if (ot < q) Gc[ot * LD + r] = gt[i];
+                if (ob < q) Gc[ob * LD + r] = gb[i];
+            }
+        }
+    }
+    __syncthreads();
     return sweep;
 }
 
