@@ -1368,79 +1368,6 @@ __device__ __forceinline__ void sdp_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// z vector of a work item as in sdp_item_z, zero beyond q, with the reads of eight entries issued
-// together.  Reads run up to 7 entries past q inside the LDS allocation; those products are
-// replaced by zeros.
-template <int QM>
-__device__ __forceinline__ void sdp_item_z_wide(const SdpWork w, int LD, int e, int npair, double (&z)[QM],
-                                                double& lf, double& scale, int& slot) {
-    const int q = __builtin_amdgcn_readfirstlane(w.q);
-    const bool k0 = e < npair, k1 = !k0 && e < npair + q, k2 = e == npair + q;
-    int i, j;
-    sdp_tri_index(k0 ? e : 0, i, j);
-    const int ia = k1 ? e - npair : i;
-    const lds_f64* A = (k0 || k1) ? w.X + ia * LD : w.rp;
-    const lds_f64* B = k0 ? w.X + j * LD : w.rp;
-    double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-    for (int a0 = 0; a0 < QM; a0 += 8) {
-        if (a0 < q) {
-            double av[8], bv[8], sv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = A[a0 + u]; bv[u] = B[a0 + u]; sv[u] = w.sq[a0 + u]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const double zz = (a0 + u < q) ? av[u] * bv[u] : 0.0;
-                z[a0 + u] = zz;
-                if (u & 1) acc1 = fma(zz, (a0 + u < q) ? sv[u] : 0.0, acc1);
-                else acc0 = fma(zz, (a0 + u < q) ? sv[u] : 0.0, acc0);
-            }
-            SDP_READS_FIRST(24, 24);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) z[a0 + u] = 0.0;
-        }
-    }
-    const double ipi = w.ip[ia], ipj = w.ip[j];
-    scale = ((k0 || k1) ? ipi : 1.0) * (k0 ? ipj : 1.0);
-    lf = acc0 + acc1;
-    slot = k0 ? i * LD + j : k1 ? -1 - ia : k2 ? -1 - q : INT_MIN;
-}
-
-// z^T K' z with K'(b, a), a > b, at Kt[b * LD + a]: row b is walked in groups of 16 contiguous
-// entries whose reads are issued together.  A group may run past column q - 1 into the padding
-// column, the following row or the matrix behind w.H: the numbers there meet the zeros of z (the
-// caller clears the padding columns, which nothing else ever writes).
-template <int QM>
-__device__ __forceinline__ double sdp_quadform_wide(const double (&z)[QM], const SdpWork w, int LD, int q) {
-    double tot = 0.0;
-    const lds_f64* Kt = w.H;
-#pragma unroll
-    for (int b = 0; b < QM; ++b) {
-        if (b < q) {
-            const lds_f64* row = Kt + b * LD;
-            double i0 = 0.25 * w.sq[b] * z[b], i1 = 0.0;
-#pragma unroll
-            for (int a0 = b + 1; a0 < QM; a0 += 16) {
-                if (a0 < q) {
-                    constexpr int dummy = 0;
-                    double kv[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) kv[u] = (a0 + u < QM) ? row[a0 + u] : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const double zz = z[(a0 + u < QM) ? a0 + u : dummy];
-                        if (a0 + u < QM) { if (u & 1) i1 = fma(kv[u], zz, i1); else i0 = fma(kv[u], zz, i0); }
-                    }
-                    SDP_READS_FIRST(16, 16);
-                }
-            }
-            tot = fma(z[b], i0 + i1, tot);
-        }
-    }
-    return 2.0 * tot;
-}
-
 // Cholesky of A (lower triangle of w.H) and the solve A step = grad by the first wave alone:
 // lane i keeps row i in registers, pivots and multipliers travel through the scalar unit.  Rows
 // and columns past q hold zeros, so only the outer loops test q.  L goes back to w.H (lower).
@@ -1532,40 +1459,103 @@ __device__ __forceinline__ int sdp_chol_solve_wave0(const SdpWork w) {
     return fail;
 }
 
-// The quadratic forms of the register path spread over T threads (an item keeps its z vector in
-// registers, so the loops are unrolled for the largest q), then the factorisation and the solves
-// in the first wave.  Same outputs as sdp_newton_dir_reg.
+// The quadratic forms of all work items on the matrix pipe, 16 items per wave at a time.  With
+// K2 = the upper triangle of K' (entries above the diagonal doubled, diagonal sq / 2) and the z
+// vectors of the 16 items as the columns of Z, z^T K' z = z^T (K2 z) and K2 Z is a product of a
+// q x q triangle with a q x 16 matrix: row tile I needs the k steps from 4 I on.  Lane l supplies
+// Z at the k position (l >> 4) + 4 s of step s and receives row (l >> 4) + 4 (4 I + g) of the
+// product in accumulator g of row tile I -- the same 16 positions, so the z values a lane builds
+// for the right operand are the ones it multiplies the result with.  The fragments of K2 are
+// computed from sq in registers and stay there for all tiles of a call (K' never goes to LDS on
+// this path); a broadcast read of K' per multiply-add (what a loop over threads does) would keep
+// the LDS port busy four times as long as the matrix pipe is here.
+// KS = number of k steps (4 KS >= q), a template parameter so that the products form straight-line
+// code: with a bound known only at run time every product sits behind a branch and the compiler
+// moves the accumulators between register sets at each of them.
+template <int T, int KS>
+__device__ __forceinline__ void sdp_hess_items_mfma(const SdpWork w) {
+    typedef double sdp_double4 __attribute__((ext_vector_type(4)));
+    constexpr int NW = T / 64, NRT = (KS + 3) / 4;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
+    const int li = lane & 15, kg = lane >> 4;
+    const int npair = q * (q + 1) / 2, nitems = npair + q + 1, ntile = (nitems + 15) >> 4;
+    double af[NRT][KS], sqv[KS], sqr[NRT];
+#pragma unroll
+    for (int I = 0; I < NRT; ++I) { const int row = 16 * I + li; sqr[I] = w.sq[row < q ? row : 0]; }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int a = 4 * s + kg;
+        const double sa = w.sq[a < q ? a : 0];
+        sqv[s] = a < q ? sa : 0.0;
+#pragma unroll
+        for (int I = 0; I < NRT; ++I) {
+            if (s >= 4 * I) {                          // K'(b, a) = sq_a sq_b / (sq_a + sq_b)
+                const int row = 16 * I + li;
+                const bool in = row < q && a < q;
+                const double sb = sqr[I], h2 = 2.0 * sa * sb * sdp_rcp(sa + sb);
+                af[I][s] = !in ? 0.0 : (a > row) ? h2 : (a == row) ? 0.5 * sb : 0.0;
+            } else {
+                af[I][s] = 0.0;
+            }
+        }
+    }
+    for (int t = wv; t < ntile; t += NW) {
+        const int e = 16 * t + li;
+        const bool k0 = e < npair, k1 = !k0 && e < npair + q, k2 = e == npair + q;
+        int i, j;
+        sdp_tri_index(k0 ? e : 0, i, j);
+        const int ia = k1 ? e - npair : i;
+        const lds_f64* A = (k0 || k1) ? w.X + ia * LD : w.rp;
+        const lds_f64* B = k0 ? w.X + j * LD : w.rp;
+        double z[4 * NRT];
+        double lf = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4 * NRT; ++s) {
+            z[s] = 0.0;
+            if (s < KS) {
+                const int a = 4 * s + kg, ac = a < q ? a : 0;
+                const double av = A[ac], bv = B[ac];
+                z[s] = a < q ? av * bv : 0.0;
+                lf = fma(z[s], sqv[s], lf);
+            }
+        }
+        sdp_double4 acc[NRT];
+#pragma unroll
+        for (int I = 0; I < NRT; ++I) acc[I] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int I = 0; I < NRT; ++I)
+                if (s >= 4 * I) acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[I][s], z[s], acc[I], 0, 0, 0);
+        }
+        double qf = 0.0;
+#pragma unroll
+        for (int I = 0; I < NRT; ++I) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) qf = fma(z[4 * I + g], acc[I][g], qf);
+        }
+        qf += __shfl_xor(qf, 16); qf += __shfl_xor(qf, 32);
+        lf += __shfl_xor(lf, 16); lf += __shfl_xor(lf, 32);
+        const double ipi = w.ip[ia], ipj = w.ip[j];
+        const double scale = ((k0 || k1) ? ipi : 1.0) * (k0 ? ipj : 1.0);
+        const int slot = k0 ? i * LD + j : k1 ? -1 - ia : k2 ? -1 - q : INT_MIN;
+        if (kg == 0) sdp_item_store(w, slot, qf, lf, scale);
+    }
+}
+
+// The quadratic forms on the matrix pipe, 16 work items per wave at a time, then the factorisation
+// and the solves in the first wave.  Same outputs as sdp_newton_dir_reg.
 template <int T>
 __device__ int sdp_newton_dir_wide(const SdpWork w) {
     const int tid = threadIdx.x;
     const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
     __syncthreads();
     SDP_TIC(t_items);
-    for (int e = tid; e < q * q; e += T) {
-        const int a = e / q, b = e - a * q;
-        if (b < a) {
-            const double sa = w.sq[a], sb = w.sq[b];
-            w.H[b * LD + a] = sa * sb * sdp_rcp(sa + sb);
-        }
-    }
-    // The walks over K' read whole groups of 16 entries and meet the zeros of z past column q - 1:
-    // in the padding column of the matrix (even q), in the following row and, for small q, in the
-    // first rows of the matrix behind w.H (w.S).  Rows hold numbers; the padding columns hold
-    // whatever the previous kernel left in LDS, and 0 * (NaN or Inf bits) is NaN: clear them.
-    if (LD > q) {
-        for (int i = tid; i < q; i += T) { w.H[i * LD + q] = 0.0; w.S[i * LD + q] = 0.0; }
-    }
-    __syncthreads();
-    {
-        const int npair = q * (q + 1) / 2, nitems = npair + q + 1;
-        for (int e0 = tid; e0 < nitems; e0 += T) {
-            double z0[OEI_MAX_Q];
-            int s0;
-            double l0, c0;
-            sdp_item_z_wide<OEI_MAX_Q>(w, LD, e0, npair, z0, l0, c0, s0);
-            sdp_item_store(w, s0, sdp_quadform_wide<OEI_MAX_Q>(z0, w, LD, q), l0, c0);
-        }
-    }
+    static_assert(T % 64 == 0, "whole waves");
+    if (q <= 40) sdp_hess_items_mfma<T, 10>(w);
+    else if (q <= 52) sdp_hess_items_mfma<T, 13>(w);
+    else sdp_hess_items_mfma<T, 16>(w);
     __syncthreads();
     const double e0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
