@@ -595,8 +595,10 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
 }
 
 // ---- q > 32: one 256-thread workgroup per candidate ------------------------------------------------
-// LDS holds four q x q matrices (Newton factor, U and two scratch matrices; R is expressed through
-// U, see sens_direction_lean), the solver's vectors, the candidate's points and d mu/dx.  The
+// LDS holds three q x q matrices (the solver's; for the directions U and two scratch matrices: R is
+// expressed through U and the inverse of the Newton factor sits in registers, see
+// sens_direction_lean), the solver's vectors, the candidate's points and d mu/dx: 80 KB at q = 50,
+// d = 10, so that two workgroups share a compute unit and fill each other's barrier waits.  The
 // q^2-sized tables (dSigma/dx: q*d*q doubles, the kernel-derivative factors, the diagonal blocks
 // Dg) live in a per-candidate block of global memory `tabs`; they are written once, then read
 // row-wise by the contraction of every direction (L2-resident).  Fits every q <= 64 for d <= 12.
@@ -604,12 +606,13 @@ __host__ __device__ inline size_t hess_wide_table_doubles(int q, int d) {
     return (size_t)q * d * q + 2 * (size_t)q * q + (size_t)q * d * d;      // DS | k1s | k2s | Dg
 }
 __host__ __device__ inline size_t hess_wide_lds_doubles(int q, int d) {
-    // H S X V | 15 solver vectors + 8 scalars | mu, 9 sensitivity vectors, dNmu, utc, utmu, wv, scl | xq | dmuT
-    return (size_t)4 * q * sdp_ld(q) + (size_t)(SDP_NVEC + 1 + SENS_NVEC + 5) * sdp_vlen(q) + 8 + 2 * (size_t)q * d;
+    // H S X | 15 solver vectors + 8 scalars | mu, 9 sensitivity vectors | xq | dmuT
+    // (dNmu, utc, utmu, wv, scl of the directions take the place of solver vectors that are dead by then)
+    return (size_t)3 * q * sdp_ld(q) + (size_t)(SDP_NVEC + 1 + SENS_NVEC) * sdp_vlen(q) + 8 + 2 * (size_t)q * d;
 }
 
 template <int T>
-__global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, double fmin, int n,
+__global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise, double fmin, int n,
                                                  int npad, int q, int RP,
                                                  const double* __restrict__ Xtrain,
                                                  const double* __restrict__ alpha,
@@ -623,12 +626,15 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
                                                  double* __restrict__ Hout, int* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     OEI_LDS_POISON(sm);
+#ifdef OEI_HESS_TIMING
+    const long long t_kernel0 = clock64();
+#endif
     const int VL = sdp_vlen(q), LD = sdp_ld(q), ML = q * LD, d = kp.d, dp = d + 1, qd = q * d;
     SdpWork w;
     w.q = q; w.LD = LD;
     lds_f64* ptr = (lds_f64*)sm;
-    w.H = ptr; ptr += ML;  w.S = ptr; ptr += ML;  w.X = ptr; ptr += ML;  w.V = ptr; ptr += ML;
-    w.R = w.Kt = nullptr;
+    w.H = ptr; ptr += ML;  w.S = ptr; ptr += ML;  w.X = ptr; ptr += ML;
+    w.V = w.R = w.Kt = nullptr;
     w.p = ptr; ptr += VL;  w.pn = ptr; ptr += VL;  w.s = ptr; ptr += VL;  w.dl = ptr; ptr += VL;
     w.sq = ptr; ptr += VL; w.grad = ptr; ptr += VL; w.step = ptr; ptr += VL; w.tv = ptr; ptr += VL;
     w.sv = ptr; ptr += VL; w.rp = ptr; ptr += VL;  w.ci = ptr; ptr += VL;  w.ip = ptr; ptr += VL;
@@ -637,11 +643,12 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     lds_f64* mu = ptr; ptr += VL;
     SensVec sv;
     sens_carve(sv, ptr, q); ptr += SENS_NVEC * VL;
-    lds_f64* dNmu = ptr; ptr += VL;
-    lds_f64* utc = ptr; ptr += VL;
-    lds_f64* utmu = ptr; ptr += VL;
-    lds_f64* wv = ptr; ptr += VL;
-    lds_f64* scl = ptr; ptr += VL;
+    // written only after the solve, in the place of solver vectors nothing reads any more
+    lds_f64* dNmu = w.pn;
+    lds_f64* utc = w.grad;
+    lds_f64* utmu = w.tv;
+    lds_f64* wv = w.wp;
+    lds_f64* scl = w.rs;
     lds_f64* xq = ptr; ptr += qd;
     lds_f64* dmuT = ptr;
     const int tid = threadIdx.x;
@@ -660,8 +667,8 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     if (tid < q) w.p[tid] = p_in[b * q + tid];
     __syncthreads();
 
-    // w.X and w.V (adjacent) stage the training-point chunks of the Dg pre-pass
-    hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, w.X, (size_t)2 * ML, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    // the three matrices (adjacent, nothing in them yet) stage the training-point chunks of the Dg pre-pass
+    hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, w.H, (size_t)3 * ML, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
     build_tables<T>(kp, q, xq, Gb, RP, mu, DS, dmuT, k1s, k2s);
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, c = e - a * q;
@@ -679,6 +686,9 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     __syncthreads();
 
     // ---- state at the optimum: U, the factor of -hess g, c, t1 ----------------------------------
+#ifdef OEI_HESS_TIMING
+    const long long t_state0 = clock64();
+#endif
     int sweeps = 0;
     int st = sdp_factor<T, 0>(w) ? 2 : 0;
     const double g = st ? -INFINITY : sdp_eval<T, 0>(w, w.p, sweeps, false);
@@ -686,6 +696,9 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     if (!st) {
         if (sdp_newton_dir<T, 0>(w)) st = 2;          // reads U from w.X; w.S (Lc) is free afterwards
     }
+#ifdef OEI_HESS_TIMING
+    const long long t_state1 = clock64();
+#endif
     if (st) {
         // every slice answers for its own rows: the slices repeat the same solve, but one that
         // breaks down alone must not leave its rows unwritten behind a status of 0
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
     {
         const int lane = tid & 63, wave = tid >> 6;
         // L^-1 for the directions' solves, column j by lane j of the first wave, into w.X (free
-        // until the first direction); copied over L behind the barrier
+        // until the first direction); every thread takes its share into registers behind the barrier
         if (wave == 0) {
             for (int e = lane; e < q * LD; e += 64) w.X[e] = 0.0;
             sdp_wave_sync();
@@ -744,8 +757,16 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
         }
     }
     __syncthreads();
-    for (int e = tid; e < q * LD; e += T) w.H[e] = w.X[e];
+    double lr[16], lc[16];
+    sens_linv_regs(w.X, q, LD, lr, lc);
 
+#ifdef OEI_HESS_TIMING
+    long long sens_cyc[12] = {};
+    const long long t_dirs0 = clock64();
+    sens_cyc[11] = t_dirs0 - t_kernel0;
+    sens_cyc[8] = t_state0 - t_kernel0;
+    sens_cyc[9] = t_state1 - t_state0;
+#endif
     // ---- one sensitivity solve per direction, fused with the contraction ------------------------
     for (int al = slice; al < qd; al += nslice) {
         const int a = al / d, l = al - a * d;
@@ -754,16 +775,29 @@ __global__ __launch_bounds__(T) void k_hess_wide(KernParams kp, double noise, do
             sv.dmu[tid] = (tid == a) ? dmuT[al] : 0.0;
             wv[tid] = DS[(size_t)al * q + tid];
         }
-        sens_direction_lean<T>(w, sv, a, wv, scl, utc);
+#ifdef OEI_HESS_TIMING
+        sens_direction_lean<T>(w, sv, a, wv, scl, utc, lr, lc, sens_cyc);
+        long long sens_t0 = clock64();
+#else
+        sens_direction_lean<T>(w, sv, a, wv, scl, utc, lr, lc);
+#endif
         {
             const int ri = tid >> 2, row = ri < q ? ri : 0;
-            const double v = quad_row_sum(q, [&](int k) { return w.V[row * LD + k] * utmu[k]; });
+            const double v = quad_row_sum(q, [&](int k) { return w.H[row * LD + k] * utmu[k]; });
             if (ri < q && (tid & 3) == 0) dNmu[ri] = v;                        // dN mu = Y (U^T mu)
         }
         __syncthreads();
-        hess_contract<true>(tid, T, kp, q, RP, a, l, w.V, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
+        hess_contract<true>(tid, T, kp, q, RP, a, l, w.H, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
                             (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
+        SENS_STAMP(7);
     }
+#ifdef OEI_HESS_TIMING
+    __syncthreads();
+    if (b == 0 && slice == 0 && tid == 0) {
+        sens_cyc[10] = clock64() - t_dirs0;
+        for (int i = 0; i < 12; ++i) Hb[i] = (double)sens_cyc[i];
+    }
+#endif
     if (slice == 0 && tid == 0 && status && sdp_status) atomicMax(status + b, sdp_status[b]);   // status[] starts at 0
 }
 
@@ -1152,7 +1186,9 @@ extern "C" int oei_hessian_batched(oei_model* m, int B, int q, const double* X, 
         const size_t gbytes = (size_t)Bc * RP * RP * sizeof(double);
         // small batches: several workgroups per candidate share its q d directions (the chip has
         // 256 CUs and these kernels run one workgroup per CU)
-        int nslice = (Bc <= 128) ? 256 / Bc : 1;
+        // (the wide kernel fits two per CU when its LDS allows)
+        const int slots = (wide && 2 * lds <= (size_t)160 * 1024) ? 512 : 256;
+        int nslice = (2 * Bc <= slots) ? slots / Bc : 1;
         if (nslice > 8) nslice = 8;
         const size_t sbytes = !wide ? (size_t)Bc * hess_state_doubles(q) * sizeof(double) + (size_t)Bc * sizeof(int) + 16
                                     : (size_t)Bc * nslice * hess_wide_table_doubles(q, d) * sizeof(double) + 16;

@@ -416,17 +416,56 @@ __device__ __forceinline__ double quad_row_sum(int q, F term) {
 //   R^T diag(dp) R  = U^T diag(dp / p^2) U + h rp^T + rp h^T + (sum dp) rp rp^T,  h = U^T (dp / p),
 //   rd = R^T dp = h + (sum dp) rp,   so  R^T dD R = U^T diag(dp / p^2) U - (sum dp) rp rp^T.
 // In: sv.dmu and the perturbation in rank-2 form dS = e_a v'^T + v' e_a^T through wv = U^T v'
-// (in LDS; overwritten).  Like the YFORM of sens_direction it stops at Y = U Z: out Y in w.V,
+// (in LDS; overwritten).  Like the YFORM of sens_direction it stops at Y = U Z: out Y in w.H,
 // sv.w1 = N dc, sv.w2 = dN c = Y utc (utc = U^T c), sv.dp.
-// Needs L^-1 in w.H (full, zeros above the diagonal), w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1; scl is [q] scratch.
+// Needs w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1 and, in registers, the thread's share of L^-1 (L the
+// factor of -hess g): thread (row, part) = (tid >> 2, tid & 3) holds lr[j] = L^-1[row][part + 4 j]
+// and lc[j] = L^-1[part + 4 j][row], zeros past q (sens_linv_regs).  scl is [q] scratch.
+// Three q x q matrices of LDS: U (w.S) and the two scratch matrices w.X and w.H.
+__device__ __forceinline__ void sens_linv_regs(const lds_f64* Li, int q, int LD, double (&lr)[16], double (&lc)[16]) {
+    const int ri = threadIdx.x >> 2, part = threadIdx.x & 3, row = ri < q ? ri : 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = part + 4 * j, kc = k < q ? k : 0;
+        const double a = Li[row * LD + kc], b = Li[kc * LD + row];
+        lr[j] = (k < q && k <= row) ? a : 0.0;
+        lc[j] = (k < q && k >= row) ? b : 0.0;
+    }
+}
+// sum_k m[j(k)] x[k] over the thread's k = part, part + 4, ... and over the four threads of the row
+__device__ __forceinline__ double quad_reg_sum(int q, const double (&m)[16], const lds_f64* x) {
+    const int part = threadIdx.x & 3;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        if (4 * j < q) {
+            const int k0 = part + 4 * j, k1 = k0 + 4;
+            const double x0 = x[k0 < q ? k0 : 0], x1 = x[k1 < q ? k1 : 0];
+            acc0 = fma(m[j], x0, acc0);              // m is zero where k >= q
+            acc1 = fma(m[j + 1], x1, acc1);
+        }
+    }
+    double acc = acc0 + acc1;
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    return acc;
+}
 template <int T>
 __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensVec sv, int a_dir,
-                                                    lds_f64* wv, lds_f64* scl, const lds_f64* utc) {
+                                                    lds_f64* wv, lds_f64* scl, const lds_f64* utc,
+                                                    const double (&lr)[16], const double (&lc)[16]
+#ifdef OEI_HESS_TIMING
+                                                    , long long (&sens_cyc)[12]
+#endif
+                                                    ) {
+#ifdef OEI_HESS_TIMING
+    long long sens_t0 = clock64();
+#endif
     const int tid = threadIdx.x;
     const int q = w.q, LD = w.LD;
     const lds_f64* U = w.S;
     lds_f64* Tc = w.X;
-    lds_f64* Tb = w.V;
+    lds_f64* Tb = w.H;
     // the q-term sums: four threads per row (T = 256 >= 4 q)
     static_assert(T == 256, "four threads per row need 4 q <= T for every q <= 64");
     const int ri = tid >> 2, row = ri < q ? ri : 0;
@@ -441,12 +480,14 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         }
     }
     __syncthreads();
+    SENS_STAMP(0);
     wg4_mm_mfma<false, true, true>(q, LD, Tc, U, Tb, w.sq);    // Tb = M1' = ZS diag(sq) U^T
     {
         const double v = quad_row_sum(q, [&](int k) { return Tc[row * LD + k] * sv.t1[k]; });
         if (rown) sv.t2[ri] = v;
     }
     __syncthreads();
+    SENS_STAMP(1);
     {
         // rhs_i = dmu_i + sum_a R[i][a] sq[a] (M1[a][i] - 2 t2[a]),  M1[a][i] = M1'[a][i] / p_i + t2[a]
         const double ipi = w.ip[row];
@@ -457,17 +498,16 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         if (rown) w.step[ri] = sv.dmu[ri] + acc;
     }
     __syncthreads();
-    // (-hess g) x = rhs through L^-1, which the caller keeps in w.H as a full matrix (zeros above
-    // the diagonal): two matrix-vector products, a row per thread.  (A substitution with L costs
-    // 2 q dependent steps in one wave, each a broadcast through the scalar unit, or two barriers
-    // per component across the workgroup.)
+    // (-hess g) x = rhs through L^-1: two matrix-vector products, four threads per row, the
+    // matrix entries in registers.  (A substitution with L costs 2 q dependent steps in one wave,
+    // each a broadcast through the scalar unit, or two barriers per component across the workgroup.)
     {
-        const double y = quad_row_sum(q, [&](int k) { return w.H[row * LD + k] * w.step[k]; });    // y = L^-1 rhs
+        const double y = quad_reg_sum(q, lr, w.step);                                  // y = L^-1 rhs
         if (rown) sv.rd[ri] = y;
     }
     __syncthreads();
     {
-        const double x = quad_row_sum(q, [&](int k) { return w.H[k * LD + row] * sv.rd[k]; });     // L^-T y
+        const double x = quad_reg_sum(q, lc, sv.rd);                                   // L^-T y
         if (rown) {
             const double dp = -x, ipi = w.ip[ri];
             sv.dp[ri] = dp;
@@ -476,6 +516,7 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         }
     }
     __syncthreads();
+    SENS_STAMP(2);
     double sdp = 0.0;
     for (int i = 0; i < q; ++i) sdp += sv.dp[i];
     {
@@ -484,18 +525,21 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     }
     wg4_mm_mfma<true, false, true>(q, LD, U, U, Tb, scl);      // Tb = U^T diag(dp / p^2) U
     __syncthreads();
+    SENS_STAMP(3);
     for (int e = tid; e < q * q; e += T) {                     // Z = ZS + Phi o (R^T dD R) / 4
         const int a = e / q, b = e - a * q;
         const double acc = Tb[a * LD + b] - sdp * w.rp[a] * w.rp[b];
         Tc[a * LD + b] += acc * (0.5 * sdp_rcp(w.sq[a] + w.sq[b]));
     }
     __syncthreads();
+    SENS_STAMP(4);
     wg4_mm_mfma<false, false, false>(q, LD, U, Tc, Tb);        // Tb = Y = U Z
     {
         const double v = quad_row_sum(q, [&](int k) { return Tc[row * LD + k] * sv.t1[k]; });      // Z t1
         if (rown) sv.t2[ri] = v;
     }
     __syncthreads();
+    SENS_STAMP(5);
     {
         // dc = dmu + sum_a R[i][a] sq[a] (rd[a] - 2 t2[a])
         const double ipi = w.ip[row];
@@ -520,4 +564,5 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
         }
     }
     __syncthreads();
+    SENS_STAMP(6);
 }
