@@ -370,10 +370,10 @@ __device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int
 // flight together, then the matrix instructions.  No workgroup barrier inside the pass.  (With
 // chunks of 36 staged per workgroup the pass was three barriers and five serial global-load
 // latencies per chunk: 86 k of a candidate's 530 k cycles.)  Leaves a barrier behind.
-template <int T>
+template <int T, typename DP>
 __device__ __forceinline__ void hess_dg_prepass_mfma(const KernParams& kp, int n, int npad, int q,
                                                      const lds_f64* xq, const lds_f64* pv, lds_f64* tab,
-                                                     size_t tabsz, lds_f64* Dg, lds_f64* wscratch, size_t wsz,
+                                                     size_t tabsz, DP Dg, lds_f64* wscratch, size_t wsz,
                                                      const double* __restrict__ Xtrain,
                                                      const double* __restrict__ alpha,
                                                      const double* __restrict__ Wrows
@@ -506,10 +506,46 @@ __device__ __forceinline__ void hess_dg_selfcov(const KernParams& kp, int q, con
     }
 }
 
+// The same sums with the tables in global memory (the wide kernel): the weights M11 k2s and
+// M11 k1s go through two q x LD LDS matrices first (zero at c = a), so that the q d^2 sums of q
+// terms read LDS only.  Contains a barrier; the caller synchronises before the matrices are reused.
+template <int T>
+__device__ __forceinline__ void hess_dg_selfcov_staged(const KernParams& kp, int q, int LD, const lds_f64* xq,
+                                                       const double* M11, const double* k1s, const double* k2s,
+                                                       lds_f64* W2, lds_f64* W1, double* Dg) {
+    const int d = kp.d;
+    for (int e = threadIdx.x; e < q * q; e += T) {
+        const int a = e / q, c = e - a * q;
+        const double m = (a == c) ? 0.0 : M11[e];
+        W2[a * LD + c] = m * k2s[e];
+        W1[a * LD + c] = m * k1s[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < q * d * d; e += T) {
+        const int a = e / (d * d), rem = e - a * d * d, l = rem / d, m2 = rem - l * d;
+        const double xl = xq[a * d + l], xm = xq[a * d + m2];
+        double s0 = 0.0, s1 = 0.0, t1 = 0.0;
+        int c = 0;
+        for (; c + 2 <= q; c += 2) {
+            const double w0 = W2[a * LD + c], w1 = W2[a * LD + c + 1];
+            const double l0 = xl - xq[c * d + l], l1 = xl - xq[(c + 1) * d + l];
+            const double m0 = xm - xq[c * d + m2], m1 = xm - xq[(c + 1) * d + m2];
+            s0 = fma(w0 * l0, m0, s0);
+            s1 = fma(w1 * l1, m1, s1);
+            if (l == m2) t1 += W1[a * LD + c] + W1[a * LD + c + 1];
+        }
+        for (; c < q; ++c) {
+            s0 = fma(W2[a * LD + c] * (xl - xq[c * d + l]), xm - xq[c * d + m2], s0);
+            if (l == m2) t1 += W1[a * LD + c];
+        }
+        Dg[e] += 2.0 * ((s0 + s1) * kp.inv_ls2[l] * kp.inv_ls2[m2] + t1 * kp.inv_ls2[l]);
+    }
+}
+
 // Row (a,l) of the Hessian from the direction's dN (q x LD), w1, w2, dN mu: the contraction with
 // every dOmega_(b,m) plus d2<Omega,M>/dx2 at fixed M.  `nth` threads numbered `tid` share the row.
 // WVFORM: `dN` holds Y = U Z and `DS` the table WV[b,m] = U^T v'_(b,m) in place of dSigma/dx, so
-// that <dN, dS_(b,m)> = 2 (dN v')_b = 2 Y[b,:] . WV[b,m].
+// that <dN, dS_(b,m)> = 2 (dN v')_b = 2 Y[b,:] . WV[b,m]  (in LDS: row-major; in global memory: transposed).
 template <bool WVFORM = false, typename MP, typename TP>
 __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams& kp, int q, int RP,
                                               int a, int l, const lds_f64* dN, int LD,
@@ -570,20 +606,21 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
             const int bb = bm / d;
             double acc = 0.0;
             const auto dsrow = DS + (size_t)bm * q;
-            if constexpr (WVFORM) {          // table in global memory (q > 32): ten loads in flight
+            if constexpr (WVFORM) {          // table in global memory, transposed (q > 32): ten loads in flight
                 double acc1 = 0.0;
+                const auto col = DS + bm;                    // entry c of row bm at col[c * qd]
                 int c = 0;
                 for (; c + 10 <= q; c += 10) {
                     double tv[10];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) tv[u] = dsrow[c + u];
+                    for (int u = 0; u < 10; ++u) tv[u] = col[(size_t)(c + u) * qd];
 #pragma unroll
                     for (int u = 0; u < 10; u += 2) {
                         acc = fma(dN[bb * LD + c + u], tv[u], acc);
                         acc1 = fma(dN[bb * LD + c + u + 1], tv[u + 1], acc1);
                     }
                 }
-                for (; c < q; ++c) acc = fma(dN[bb * LD + c], dsrow[c], acc);
+                for (; c < q; ++c) acc = fma(dN[bb * LD + c], col[(size_t)c * qd], acc);
                 acc = 2.0 * (acc + acc1);
             } else {
 #pragma unroll 4
@@ -600,15 +637,65 @@ __device__ __forceinline__ void hess_contract(int tid, int nth, const KernParams
 // sens_direction_lean), the solver's vectors, the candidate's points and d mu/dx: 80 KB at q = 50,
 // d = 10, so that two workgroups share a compute unit and fill each other's barrier waits.  The
 // q^2-sized tables (dSigma/dx: q*d*q doubles, the kernel-derivative factors, the diagonal blocks
-// Dg) live in a per-candidate block of global memory `tabs`; they are written once, then read
-// row-wise by the contraction of every direction (L2-resident).  Fits every q <= 64 for d <= 12.
+// Dg) live in a per-candidate block of global memory `tabs`; they are written once, then read by
+// the contraction of every direction (L2-resident).  The table the contraction walks, WV = rows
+// U^T v'_(b,m), is stored transposed (entry c of row (b,m) at WVT[c q d + (b,m)]): a thread owns a
+// row, so the 64 rows a wave reads at a time are 512 contiguous bytes per entry; row-major, every
+// load instruction touched 64 cache lines and the contraction was half of a direction's time.
+// Fits every q <= 64 for d <= 12.
 __host__ __device__ inline size_t hess_wide_table_doubles(int q, int d) {
-    return (size_t)q * d * q + 2 * (size_t)q * q + (size_t)q * d * d;      // DS | k1s | k2s | Dg
+    return 2 * (size_t)q * d * q + 2 * (size_t)q * q + (size_t)q * d * d;  // DS | k1s | k2s | Dg | WVT
 }
 __host__ __device__ inline size_t hess_wide_lds_doubles(int q, int d) {
     // H S X | 15 solver vectors + 8 scalars | mu, 9 sensitivity vectors | xq | dmuT
     // (dNmu, utc, utmu, wv, scl of the directions take the place of solver vectors that are dead by then)
     return (size_t)3 * q * sdp_ld(q) + (size_t)(SDP_NVEC + 1 + SENS_NVEC) * sdp_vlen(q) + 8 + 2 * (size_t)q * d;
+}
+
+// Rows (b,m) of the q d x q table DS in global memory (entry c = b halved) times U (q x q, LDS) on
+// the matrix pipe, 16 rows per wave at a time; the product goes to WVT transposed (q x q d).
+// KS = number of k steps (4 KS >= q), a template parameter for straight-line code.
+template <int T, int KS>
+__device__ __forceinline__ void hess_table_transform(int q, int LD, int d, const lds_f64* U, const double* DS,
+                                                     double* WVT) {
+    constexpr int NCT = (KS + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kg = lane >> 4, qd = q * d;
+    for (int I = wave; 16 * I < qd; I += T / 64) {
+        const int bm = 16 * I + li;
+        const bool rin = bm < qd;
+        const int bmc = rin ? bm : 0, bb = bmc / d;
+        const double* row = DS + (size_t)bmc * q;
+        double av[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 4 * s + kg;
+            const double x = row[c < q ? c : 0];
+            av[s] = (rin && c < q) ? (c == bb ? 0.5 * x : x) : 0.0;
+        }
+        sens_double4 acc[NCT];
+#pragma unroll
+        for (int J = 0; J < NCT; ++J) acc[J] = (sens_double4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int c = 4 * s + kg, cc = c < q ? c : 0;
+#pragma unroll
+            for (int J = 0; J < NCT; ++J) {
+                const int j = 16 * J + li;
+                const double u = U[cc * LD + (j < q ? j : 0)];
+                acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], (c < q && j < q) ? u : 0.0, acc[J], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int r = 16 * I + kg + 4 * g;
+#pragma unroll
+            for (int J = 0; J < NCT; ++J) {
+                const int j = 16 * J + li;
+                if (r < qd && j < q) WVT[(size_t)j * qd + r] = acc[J][g];
+            }
+        }
+    }
 }
 
 template <int T>
@@ -663,13 +750,34 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
     double* k1s = DS + (size_t)qd * q;
     double* k2s = k1s + (size_t)q * q;
     double* Dg = k2s + (size_t)q * q;
+    double* WVT = Dg + (size_t)qd * d;
     for (int e = tid; e < qd; e += T) xq[e] = Xq[b * qd + e];
     if (tid < q) w.p[tid] = p_in[b * q + tid];
     __syncthreads();
 
-    // the three matrices (adjacent, nothing in them yet) stage the training-point chunks of the Dg pre-pass
-    hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, w.H, (size_t)3 * ML, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    // the three matrices (adjacent, nothing in them yet) are the scratch of the Dg pre-pass: a quarter
+    // per wave for the matrix-pipe form (a point's d + 1 rows fit the 16-row tile), else one staging area
+    if (d < 16) {
+#ifdef OEI_HESS_TIMING
+        long long pre_cyc[4] = {0, 0, 0, 0};
+#endif
+        const size_t wsz = (size_t)3 * ML / (T / 64);
+        hess_dg_prepass_mfma<T>(kp, n, npad, q, xq, w.p, (lds_f64*)nullptr, 0, Dg, w.H + (tid >> 6) * wsz, wsz, Xtrain, alpha,
+                                Wm + b * (size_t)q * npad
+#ifdef OEI_HESS_TIMING
+                                , pre_cyc
+#endif
+                                );
+    } else {
+        hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, w.H, (size_t)3 * ML, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
+    }
+#ifdef OEI_HESS_TIMING
+    const long long t_pre1 = clock64();
+#endif
     build_tables<T>(kp, q, xq, Gb, RP, mu, DS, dmuT, k1s, k2s);
+#ifdef OEI_HESS_TIMING
+    const long long t_pre2 = clock64();
+#endif
     for (int e = tid; e < q * q; e += T) {
         const int a = e / q, c = e - a * q;
         double t = 0.0;
@@ -682,7 +790,7 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
         w.S[a * LD + c] = kp.variance * k0 - gsym(Gb, RP, a * dp, c * dp) + (a == c ? noise : 0.0);
     }
     if (tid < q) w.dl[tid] = mu[tid] - fmin;
-    hess_dg_selfcov<T>(kp, q, xq, M11, (const double*)k1s, (const double*)k2s, Dg);
+    hess_dg_selfcov_staged<T>(kp, q, LD, xq, M11, (const double*)k1s, (const double*)k2s, w.H, w.X, Dg);
     __syncthreads();
 
     // ---- state at the optimum: U, the factor of -hess g, c, t1 ----------------------------------
@@ -722,11 +830,14 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
     __syncthreads();
     // Row (b,m) of the dSigma/dx table becomes U^T v'_(b,m) (half weight at j = b), in place: the
     // direction's own input and what the contraction of every other direction meets (see
-    // k_hess_dirs).  A wave per row, lane t = entry t; the row is overwritten after all lanes read it.
+    // k_hess_dirs).
     if (tid < q) {
         utc[tid] = lds_dot(w.S + tid, LD, sv.c, 1, q);
         utmu[tid] = lds_dot(w.S + tid, LD, mu, 1, q);
     }
+#ifdef OEI_HESS_TIMING
+    long long t_linv1 = 0;
+#endif
     {
         const int lane = tid & 63, wave = tid >> 6;
         // L^-1 for the directions' solves, column j by lane j of the first wave, into w.X (free
@@ -744,21 +855,19 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
                 }
             }
         }
-        for (int bm = wave; bm < qd; bm += T / 64) {
-            const int bb = bm / d;
-            double* row = DS + (size_t)bm * q;
-            double acc = 0.0;
-            if (lane < q) {
-#pragma unroll 4
-                for (int c = 0; c < q; ++c) acc = fma(w.S[c * LD + lane], row[c] * (c == bb ? 0.5 : 1.0), acc);
-            }
-            sdp_wave_sync();
-            if (lane < q) row[lane] = acc;
-        }
+#ifdef OEI_HESS_TIMING
+        t_linv1 = clock64();
+#endif
+        if (q <= 40) hess_table_transform<T, 10>(q, LD, d, w.S, DS, WVT);
+        else if (q <= 52) hess_table_transform<T, 13>(q, LD, d, w.S, DS, WVT);
+        else hess_table_transform<T, 16>(q, LD, d, w.S, DS, WVT);
     }
     __syncthreads();
     double lr[16], lc[16];
     sens_linv_regs(w.X, q, LD, lr, lc);
+#ifdef OEI_HESS_TIMING
+    const long long extra_cyc[4] = {t_pre1 - t_kernel0, t_pre2 - t_pre1, t_linv1 - t_state1, 0};
+#endif
 
 #ifdef OEI_HESS_TIMING
     long long sens_cyc[12] = {};
@@ -771,9 +880,17 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
     for (int al = slice; al < qd; al += nslice) {
         const int a = al / d, l = al - a * d;
         __syncthreads();
+        // the row's T_al . T_bm entries come from the candidate's Gram block in global memory (too
+        // large to stay cached across a batch): ask for them before the solve
+        double ttpre[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int bm = min(tid + T * u, qd - 1), bb = bm / d, m2 = bm - bb * d;
+            ttpre[u] = gsym(Gb, RP, a * dp + 1 + l, bb * dp + 1 + m2);
+        }
         if (tid < q) {
             sv.dmu[tid] = (tid == a) ? dmuT[al] : 0.0;
-            wv[tid] = DS[(size_t)al * q + tid];
+            wv[tid] = WVT[(size_t)tid * qd + al];
         }
 #ifdef OEI_HESS_TIMING
         sens_direction_lean<T>(w, sv, a, wv, scl, utc, lr, lc, sens_cyc);
@@ -787,8 +904,8 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
             if (ri < q && (tid & 3) == 0) dNmu[ri] = v;                        // dN mu = Y (U^T mu)
         }
         __syncthreads();
-        hess_contract<true>(tid, T, kp, q, RP, a, l, w.H, LD, (const double*)DS, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
-                            (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb);
+        hess_contract<true>(tid, T, kp, q, RP, a, l, w.H, LD, (const double*)WVT, dmuT, sv.w1, sv.w2, dNmu, Gb, M11, xq,
+                            (const double*)k1s, (const double*)k2s, (const double*)Dg, Hb, ttpre);
         SENS_STAMP(7);
     }
 #ifdef OEI_HESS_TIMING
@@ -796,6 +913,7 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
     if (b == 0 && slice == 0 && tid == 0) {
         sens_cyc[10] = clock64() - t_dirs0;
         for (int i = 0; i < 12; ++i) Hb[i] = (double)sens_cyc[i];
+        for (int i = 0; i < 4; ++i) Hb[12 + i] = (double)extra_cyc[i];
     }
 #endif
     if (slice == 0 && tid == 0 && status && sdp_status) atomicMax(status + b, sdp_status[b]);   // status[] starts at 0

@@ -517,8 +517,8 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     }
     __syncthreads();
     SENS_STAMP(2);
-    double sdp = 0.0;
-    for (int i = 0; i < q; ++i) sdp += sv.dp[i];
+    // sum of dp: every quad adds all q entries (a thread walking them alone: q dependent reads)
+    const double sdp = quad_row_sum(q, [&](int k) { return sv.dp[k]; });
     {
         const double h = quad_row_sum(q, [&](int k) { return U[k * LD + row] * wv[k]; });
         if (rown) sv.rd[ri] = h + w.rp[ri] * sdp;

@@ -14,10 +14,11 @@ X = torch.as_tensor(np.random.RandomState(2).uniform(-.5, .5, (B, 50, 10)), devi
 for _ in range(2):
     H, st = gp.hessian(X)
 torch.cuda.synchronize()
-c = H[0].flatten()[:12].cpu().numpy()
+c = H[0].flatten()[:16].cpu().numpy()
 names = ['ZS pass', 'M1 = ZS diag(sq) U^T, t2', 'rhs, two solves', 'rd, U^T diag U', 'Z pass', 'Y = U Z, t2', 'dc, w1, w2',
          'dN mu, contraction']
 for n_, v in zip(names, c[:8]):
     print('%-26s %10.0f cycles (all directions of the workgroup)' % (n_, v))
 print('directions in all          %10.0f' % c[10])
 print('prologue                   %10.0f  (pre-pass + tables %.0f, solver state %.0f, rest %.0f)' % (c[11], c[8], c[9], c[11] - c[8] - c[9]))
+print('pre-pass %.0f, tables %.0f, covariance + self-covariance blocks %.0f; state copies + L^-1 by wave 0 %.0f' % (c[12], c[13], c[8] - c[12] - c[13], c[14]))
