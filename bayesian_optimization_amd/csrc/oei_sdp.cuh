@@ -1325,6 +1325,16 @@ __device__ __forceinline__ int sdp_chol_solve_reg(const SdpWork w) {
     return 0;
 }
 
+// Register-path instances above this size run the quadratic forms of the Newton matrix on the
+// matrix pipe (sdp_hess_items_mfma); at Q = 20 the 16 x 4 tiles cover 384 entries of K' for 210
+// that are needed and the vector-unit form, which shares each read of K' between two items, is
+// faster (k_stage2 0.464 against 0.492 ms at q = 20, B = 2048).
+#ifndef SDP_ITEMS_MFMA_MIN_Q
+#define SDP_ITEMS_MFMA_MIN_Q 20
+#endif
+template <int T, int KS>
+__device__ __forceinline__ void sdp_hess_items_mfma(const SdpWork w);
+
 // w.step = (-hess g)^-1 grad g at the state left by sdp_eval_oe (which stays intact: U in w.X).
 // Overwrites w.H (K' above, the factor of A in and below the diagonal), w.ci, w.step.
 template <int Q, bool EXACT>
@@ -1334,15 +1344,19 @@ __device__ __forceinline__ int sdp_newton_dir_reg(const SdpWork w) {
     const int q = w.q, LD = EXACT ? (Q | 1) : w.LD;
     __syncthreads();
     SDP_TIC(t_items);
-    for (int e = tid; e < q * q; e += T) {
-        const int a = EXACT ? e / Q : e / q, b = e - a * q;
-        if (b < a) {
-            const double sa = w.sq[a], sb = w.sq[b];
-            w.H[b * LD + a] = sa * sb * sdp_rcp(sa + sb);
+    if constexpr (Q > SDP_ITEMS_MFMA_MIN_Q) {
+        sdp_hess_items_mfma<T, (Q + 3) / 4>(w);
+    } else {
+        for (int e = tid; e < q * q; e += T) {
+            const int a = EXACT ? e / Q : e / q, b = e - a * q;
+            if (b < a) {
+                const double sa = w.sq[a], sb = w.sq[b];
+                w.H[b * LD + a] = sa * sb * sdp_rcp(sa + sb);
+            }
         }
+        __syncthreads();
+        sdp_hess_items<T, Q, EXACT, (Q <= 20)>(w);
     }
-    __syncthreads();
-    sdp_hess_items<T, Q, EXACT, (Q <= 20)>(w);
     __syncthreads();
     const double e0 = w.ci[q];
     const int npair = q * (q + 1) / 2;
