@@ -28,6 +28,9 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/round_newton -o round_n
 timeout -k 10 300 python3 tools/profile_bo_loop.py --hessian=0 > $O/bo_loop_lbfgs.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/profile_bo_loop.py --nl_solver=lockstep-newton > $O/bo_loop_newton.log 2>&1 || exit 1
 timeout -k 10 400 bash tools/sdp_phase_cycles.sh 20 4096 > $O/phase_cycles.log 2>&1 || exit 1
+timeout -k 10 400 bash tools/sdp_phase_cycles.sh 32 2048 > $O/phase_cycles_q32.log 2>&1 || exit 1
+timeout -k 10 400 bash tools/sdp_phase_cycles.sh 50 256 > $O/phase_cycles_q50.log 2>&1 || exit 1
+timeout -k 10 400 bash tools/hess_wide_phase_cycles.sh 256 > $O/hess_wide_phase_cycles.log 2>&1 || exit 1
 # do fp64 matrix and vector instructions of two waves on one SIMD overlap?
 hipcc -O3 --offload-arch=gfx950 -o /tmp/mixed_pipes tools/micro/mixed_pipes.hip > $O/micro_build.log 2>&1 || exit 1
 timeout -k 10 60 /tmp/mixed_pipes > $O/micro_mixed_pipes.log 2>&1 || exit 1

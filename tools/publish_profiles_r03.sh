@@ -22,6 +22,8 @@ grep -v "$F" $O/hess_small.log > profiles/r03_hessian_small.log
 grep -v "$F" $O/lockstep.log > profiles/r03_lockstep.log
 grep -v "$F" $O/fit.log > profiles/r03_fit.log
 grep -v "$F" $O/phase_cycles.log > profiles/r03_phase_cycles.log
+(grep -v "$F" $O/phase_cycles_q32.log; grep -v "$F" $O/phase_cycles_q50.log) > profiles/r03_phase_cycles_q32_q50.log
+grep -v "$F" $O/hess_wide_phase_cycles.log > profiles/r03_hess_wide_phase_cycles.log
 if [ -f $O/micro_mixed_pipes.log ]; then cp $O/micro_mixed_pipes.log profiles/r03_micro_mixed_pipes.log; grep -v "$F" $O/warm_probe_first_order.log > profiles/r03_warm_probe_first_order.log; fi
 (grep -v "$F" $O/round_lbfgs.log; grep -v "$F" $O/round_newton.log) > profiles/r03_round.log
 (grep "^pass" $O/bo_loop_lbfgs.log | sed 's/^/--nl_solver=lockstep (default) --hessian=0: /'; grep "^pass" $O/bo_loop_newton.log | sed 's/^/--nl_solver=lockstep-newton: /') > profiles/r03_bo_loop.log
