@@ -1382,95 +1382,170 @@ __device__ __forceinline__ void sdp_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Cholesky of A (lower triangle of w.H) and the solve A step = grad by the first wave alone:
-// lane i keeps row i in registers, pivots and multipliers travel through the scalar unit.  Rows
-// and columns past q hold zeros, so only the outer loops test q.  L goes back to w.H (lower).
-// Called by every thread; contains no workgroup barrier; the caller synchronises afterwards.
-template <int QM>
-__device__ __forceinline__ int sdp_chol_solve_wave0(const SdpWork w) {
-    const int lane = threadIdx.x;
+// Block column c0 .. c0 + 15 of the factorisation by the first wave (see sdp_chol_solve_blocked).
+// Out of line: its broadcasts and lane masks live in scalar registers, and inlined into the solver
+// they pushed the scalar register file into spilling through vector lanes.
+static __device__ __noinline__ int sdp_chol_block_wave0(const SdpWork w, int c0) {
+    const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
+    const bool act = lane < q;
+    const int row = act ? lane : 0;
+    const int lanem = act ? lane : -1;           // k <= lanem: entry (lane, k) of the lower triangle exists
     int fail = 0;
-    if (lane < 64) {
-        const bool act = lane < q;
-        const int row = act ? lane : 0;
-        double a[QM];
+    double a[16];
 #pragma unroll
-        for (int k0 = 0; k0 < QM; k0 += 16) {
-            if (k0 < q) {
+    for (int u = 0; u < 16; ++u) {
+        const int k = c0 + u;
+        const double h = w.H[row * LD + (k < q ? k : 0)];
+        a[u] = (k <= lanem) ? h : 0.0;
+    }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int k = k0 + u;
-                    const double h = w.H[row * LD + k];
-                    a[k] = (act && k <= lane && k < q) ? h : 0.0;
-                }
-                SDP_READS_FIRST(16, 32);
-            } else {
+    for (int k = 0; k < 16; ++k) {
+        if (c0 + k < q) {
+            const double akk = sdp_lane_bcast(a[k], c0 + k);
+            if (!(akk > 0.0)) fail = 1;              // identical in every lane
+            const double rinv = sdp_rsq_steps<1>(akk);   // a search direction: 1e-13 is ample
+            const double lik = (lane >= c0 + k) ? a[k] * rinv : 0.0;
+            a[k] = lik;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) a[k0 + u] = 0.0;
+            for (int j = k + 1; j < 16; ++j) {
+                const double ljk = sdp_lane_bcast(lik, c0 + j);     // c0 + j <= 63; zero past q
+                a[j] -= lik * ljk;
             }
-        }
-        double dinv = 0.0;
-#pragma unroll
-        for (int k = 0; k < QM; ++k) {
-            if (k < q) {
-                const double akk = sdp_lane_bcast(a[k], k);
-                if (!(akk > 0.0)) fail = 1;              // identical in every lane
-                const double rinv = sdp_rsq(akk);
-                const double lik = (lane >= k) ? a[k] * rinv : 0.0;
-                a[k] = lik;
-                if (lane == k) dinv = rinv;
-#pragma unroll
-                for (int j0 = k + 1; j0 < QM; j0 += 8) {
-                    if (j0 < q) {
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if (j0 + u < QM) { const double ljk = sdp_lane_bcast(lik, j0 + u); a[j0 + u] -= lik * ljk; }
-                        }
-                    }
-                }
-            }
-        }
-        if (!fail) {
-            if (act) {
-#pragma unroll
-                for (int k = 0; k < QM; ++k) if (k < q && k <= lane) w.H[row * LD + k] = a[k];
-            }
-            double bv = act ? w.grad[row] : 0.0;
-#pragma unroll
-            for (int k = 0; k < QM; ++k) {                   // forward: L y = grad, column oriented
-                if (k < q) {
-                    const double yk = sdp_lane_bcast(bv * dinv, k);
-                    bv = (lane == k) ? yk : bv - a[k] * yk;  // a[k] = 0 in lanes < k
-                }
-            }
-            sdp_wave_sync();
-#pragma unroll
-            for (int k0 = 0; k0 < QM; k0 += 16) {            // column `lane` of L = row of L^T
-                if (k0 < q) {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int k = k0 + u;
-                        const double h = w.H[(k < q ? k : 0) * LD + row];
-                        a[k] = (act && k >= lane && k < q) ? h : 0.0;
-                    }
-                    SDP_READS_FIRST(16, 32);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) a[k0 + u] = 0.0;
-                }
-            }
-#pragma unroll
-            for (int k = QM - 1; k >= 0; --k) {              // backward: L^T x = y
-                if (k < q) {
-                    const double xk = sdp_lane_bcast(bv * dinv, k);
-                    bv = (lane == k) ? xk : bv - a[k] * xk;  // a[k] = 0 in lanes > k
-                }
-            }
-            if (act) w.step[lane] = bv;
+            // a step's broadcasts go through scalar registers: keep the next step's from being
+            // hoisted over this one (hundreds of live scalars, spilled through vector lanes)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int k = c0 + u;
+        if (k <= lanem) w.H[row * LD + k] = a[u];
+    }
     return fail;
+}
+
+// The two triangular solves L y = grad, L^T step = y by the first wave, L read from w.H: lane i keeps
+// row i (then column i) in registers, the components travel through the scalar unit.  Out of line
+// for the same reason as sdp_chol_block_wave0.
+template <int QM>
+static __device__ __noinline__ void sdp_tri_solves_wave0(const SdpWork w) {
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
+    const bool act = lane < q;
+    const int row = act ? lane : 0;
+    const int lanem = act ? lane : -1, lanex = act ? lane : 64;
+    sdp_wave_sync();
+    double a[QM];
+#pragma unroll
+    for (int k0 = 0; k0 < QM; k0 += 16) {
+        if (k0 < q) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u;
+                const double h = w.H[row * LD + k];          // past q: inside the allocation, masked
+                a[k] = (k <= lanem) ? h : 0.0;               // steps k >= q never run: no test on q
+            }
+            SDP_READS_FIRST(16, 32);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[k0 + u] = 0.0;
+        }
+    }
+    const double dinv = act ? sdp_rcp(w.H[row * LD + row]) : 0.0;
+    double bv = act ? w.grad[row] : 0.0;
+#pragma unroll
+    for (int k = 0; k < QM; ++k) {                   // forward: L y = grad, column oriented
+        if (k < q) {
+            const double yk = sdp_lane_bcast(bv * dinv, k);
+            bv = (lane == k) ? yk : bv - a[k] * yk;  // a[k] = 0 in lanes < k
+        }
+    }
+#pragma unroll
+    for (int k0 = 0; k0 < QM; k0 += 16) {            // column `lane` of L = row of L^T
+        if (k0 < q) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = k0 + u;
+                const double h = w.H[(k < q ? k : 0) * LD + row];
+                a[k] = (k >= lanex) ? h : 0.0;
+            }
+            SDP_READS_FIRST(16, 32);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[k0 + u] = 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = QM - 1; k >= 0; --k) {              // backward: L^T x = y
+        if (k < q) {
+            const double xk = sdp_lane_bcast(bv * dinv, k);
+            bv = (lane == k) ? xk : bv - a[k] * xk;  // a[k] = 0 in lanes > k
+        }
+    }
+    if (act) w.step[lane] = bv;
+}
+
+// Cholesky of A (lower triangle of w.H; L goes back there) and the solve A step = grad for the
+// whole workgroup, blocked by 16 columns: the first
+// wave factors a block column (lane i keeps the 16 entries of row i, pivots and multipliers through
+// the scalar unit: the unblocked algorithm restricted to the block's columns, 120 updates instead
+// of the q^2 / 2 of a full elimination step by step), then all waves subtract the panel's outer
+// product from the trailing lower triangle on the matrix pipe (16 x 16 tiles of w.H, read, updated
+// with four matrix instructions and written back), two barriers per block.  The two triangular
+// solves stay in the first wave, rows re-read from LDS.  Called by every thread; returns 1 for
+// all if A is not numerically positive definite.
+template <int T, int QM>
+__device__ __forceinline__ int sdp_chol_solve_blocked(const SdpWork w) {
+    typedef double sdp_double4 __attribute__((ext_vector_type(4)));
+    constexpr int NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int q = __builtin_amdgcn_readfirstlane(w.q), LD = __builtin_amdgcn_readfirstlane(w.LD);
+    const int nb = (q + 15) >> 4;
+    const bool act = lane < q;
+    const int row = act ? lane : 0;
+    const int li = lane & 15, kg = lane >> 4;
+    int fail = 0;
+    for (int kb = 0; kb < nb; ++kb) {
+        const int c0 = 16 * kb;
+        if (wave == 0) fail |= sdp_chol_block_wave0(w, c0);
+        if (c0 + 16 >= q) break;                             // uniform: last block, nothing behind it
+        __syncthreads();
+        const int nt = nb - 1 - kb, ntile = nt * (nt + 1) / 2;
+        for (int t = wave; t < ntile; t += NW) {
+            int ti, tj;
+            sdp_tri_index(t, ti, tj);
+            const int I = kb + 1 + ti, J = kb + 1 + tj;
+            sdp_double4 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 16 * I + kg + 4 * g, j = 16 * J + li;
+                const bool in = i < q && j <= i;
+                const double c = w.H[(in ? i : 0) * LD + (in ? j : 0)];
+                acc[g] = in ? c : 0.0;
+            }
+            const int ra = 16 * I + li, rb = 16 * J + li;
+            double av[4], bv[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int k = c0 + 4 * s4 + kg;              // < c0 + 16 < q
+                const double x = w.H[(ra < q ? ra : 0) * LD + k], y = w.H[(rb < q ? rb : 0) * LD + k];
+                av[s4] = ra < q ? -x : 0.0;
+                bv[s4] = rb < q ? y : 0.0;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 16 * I + kg + 4 * g, j = 16 * J + li;
+                if (i < q && j <= i) w.H[i * LD + j] = acc[g];
+            }
+        }
+        __syncthreads();
+    }
+    fail = __builtin_amdgcn_readfirstlane(fail);             // the same in every lane: a scalar branch
+    if (wave == 0 && !fail) sdp_tri_solves_wave0<QM>(w);
+    return __syncthreads_or(fail);
 }
 
 // The quadratic forms of all work items on the matrix pipe, 16 items per wave at a time.  With
@@ -1558,8 +1633,8 @@ __device__ __forceinline__ void sdp_hess_items_mfma(const SdpWork w) {
     }
 }
 
-// The quadratic forms on the matrix pipe, 16 work items per wave at a time, then the factorisation
-// and the solves in the first wave.  Same outputs as sdp_newton_dir_reg.
+// The quadratic forms on the matrix pipe, 16 work items per wave at a time, then the blocked
+// factorisation and the solves.  Same outputs as sdp_newton_dir_reg.
 template <int T>
 __device__ int sdp_newton_dir_wide(const SdpWork w) {
     const int tid = threadIdx.x;
@@ -1581,7 +1656,7 @@ __device__ int sdp_newton_dir_wide(const SdpWork w) {
     __syncthreads();
     SDP_TOC(4, t_items);
     SDP_TIC(t_chol);
-    const int fail = __syncthreads_or(sdp_chol_solve_wave0<OEI_MAX_Q>(w));
+    const int fail = sdp_chol_solve_blocked<T, OEI_MAX_Q>(w);
     SDP_TOC(5, t_chol);
     return fail;
 }
