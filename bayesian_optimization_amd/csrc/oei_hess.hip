@@ -370,7 +370,7 @@ __device__ __forceinline__ void hess_dg_prepass(const KernParams& kp, int n, int
 // flight together, then the matrix instructions.  No workgroup barrier inside the pass.  (With
 // chunks of 36 staged per workgroup the pass was three barriers and five serial global-load
 // latencies per chunk: 86 k of a candidate's 530 k cycles.)  Leaves a barrier behind.
-template <int T, typename DP>
+template <int T, typename DP, bool ACC = false>
 __device__ __forceinline__ void hess_dg_prepass_mfma(const KernParams& kp, int n, int npad, int q,
                                                      const lds_f64* xq, const lds_f64* pv, lds_f64* tab,
                                                      size_t tabsz, DP Dg, lds_f64* wscratch, size_t wsz,
@@ -481,7 +481,8 @@ __device__ __forceinline__ void hess_dg_prepass_mfma(const KernParams& kp, int n
             const int lo = min(l, m2), hi = max(l, m2);          // one triangle: exactly symmetric
             double v = wscratch[(ja * dp + lo) * 16 + ja * dp + hi] * kp.inv_ls2[l] * kp.inv_ls2[m2];
             if (l == m2) v += wscratch[(ja * dp + d) * 16 + ja * dp + d] * kp.inv_ls2[l];
-            Dg[(a * d + l) * d + m2] = v;
+            if (ACC) Dg[(a * d + l) * d + m2] += v;      // a later piece of the training set (same wave, same lane)
+            else Dg[(a * d + l) * d + m2] = v;
         }
         sens_sync<true>();
     }
@@ -760,14 +761,35 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
     if (d < 16) {
 #ifdef OEI_HESS_TIMING
         long long pre_cyc[4] = {0, 0, 0, 0};
+#define PRE_CYC_ARG , pre_cyc
+#else
+#define PRE_CYC_ARG
 #endif
-        const size_t wsz = (size_t)3 * ML / (T / 64);
-        hess_dg_prepass_mfma<T>(kp, n, npad, q, xq, w.p, (lds_f64*)nullptr, 0, Dg, w.H + (tid >> 6) * wsz, wsz, Xtrain, alpha,
-                                Wm + b * (size_t)q * npad
-#ifdef OEI_HESS_TIMING
-                                , pre_cyc
-#endif
-                                );
+        // The training inputs are staged once per workgroup, in as many pieces as the space behind
+        // the waves' coefficient scratch needs (two at n = 1000, d = 10), and every wave runs its
+        // points over the staged piece; staged per wave and chunk, each of a wave's 13 points
+        // fetched the whole training set again.
+        const int dl = (d + 1) | 1, na = 16 / (d + 1);
+        const size_t wsz = (size_t)max(256, 2 * na * 129);
+        const size_t cap = (size_t)3 * ML > (T / 64) * wsz ? (size_t)3 * ML - (T / 64) * wsz : 0;
+        lds_f64* wsc = w.H + (tid >> 6) * wsz;
+        lds_f64* stage = w.H + (T / 64) * wsz;
+        if (cap >= (size_t)64 * dl) {
+            const int npc = (int)(((size_t)n * dl + cap - 1) / cap);
+            int nh = (n + npc - 1) / npc;
+            nh = (nh + 3) & ~3;
+            if ((size_t)nh * dl > cap) nh = (int)(cap / dl) & ~3;
+            const double* Wr = Wm + b * (size_t)q * npad;
+            hess_dg_prepass_mfma<T, double*, false>(kp, min(nh, n), npad, q, xq, w.p, stage, cap, Dg, wsc, wsz, Xtrain, alpha, Wr PRE_CYC_ARG);
+            for (int k0 = nh; k0 < n; k0 += nh)
+                hess_dg_prepass_mfma<T, double*, true>(kp, min(nh, n - k0), npad, q, xq, w.p, stage, cap, Dg, wsc, wsz,
+                                                       Xtrain + (size_t)k0 * d, alpha + k0, Wr + k0 PRE_CYC_ARG);
+        } else {
+            const size_t wsz1 = (size_t)3 * ML / (T / 64);
+            hess_dg_prepass_mfma<T>(kp, n, npad, q, xq, w.p, (lds_f64*)nullptr, 0, Dg, w.H + (tid >> 6) * wsz1, wsz1, Xtrain, alpha,
+                                    Wm + b * (size_t)q * npad PRE_CYC_ARG);
+        }
+#undef PRE_CYC_ARG
     } else {
         hess_dg_prepass<T>(kp, n, npad, q, xq, w.p, w.H, (size_t)3 * ML, Dg, Xtrain, alpha, Wm + b * (size_t)q * npad);
     }
