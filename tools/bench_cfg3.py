@@ -1,6 +1,7 @@
 """Diagnostic: value+gradient throughput at the largest configuration (n = 1000, q = 50, d = 10) and
 the roofline figures of its dominant kernel, k_stage2<256, 0> (the wide solver path).
-Writes profiles/r03_cfg3_roofline.json when run from the repository root with --json."""
+Writes gpurun_out/r03_cfg3_roofline.json when run from the repository root with --json
+(tools/publish_profiles_r03.sh adds the counter bytes and copies it to profiles/)."""
 import json
 import os
 import sys
@@ -20,7 +21,8 @@ model = hart6.make_model(n, d=d, lengthscale=0.8)
 gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.8], 1e-6, floor_mode=1)
 gp.set_profiling(True)
 out = {}
-for B in (64, 512, 2048):
+# --only-2048: the counter passes, where every launch of a kernel should be the same size
+for B in ((2048,) if '--only-2048' in sys.argv else (64, 512, 2048)):
     X = torch.as_tensor(np.random.RandomState(2).uniform(-.5, .5, (B, q, d)), device='cuda')
     for _ in range(2):
         gp.value_grad(X)

@@ -17,6 +17,8 @@ timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o fetch --output-for
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/write -o write --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --steps 5 --warmup 1 > $O/write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/cfg3 -o cfg3 --output-format csv -- python3 tools/bench_cfg3.py --json > $O/cfg3.log 2>&1 || exit 1
 cp gpurun_out/r03_cfg3_roofline.json $O/cfg3_roofline.json || exit 1
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/cfg3_fetch -o fetch --output-format csv -- python3 tools/bench_cfg3.py --only-2048 > $O/cfg3_fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/cfg3_write -o write --output-format csv -- python3 tools/bench_cfg3.py --only-2048 > $O/cfg3_write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/hess3 -o hess3 --output-format csv -- python3 tools/bench_hessian_cfg3.py > $O/hess3.log 2>&1 || exit 1
 timeout -k 10 100 python3 tools/bench_hessian_small.py > $O/hess_small.log 2>&1 || exit 1
 timeout -k 10 200 python3 tools/bench_model.py > $O/model.log 2>&1 || exit 1

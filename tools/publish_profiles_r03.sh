@@ -13,7 +13,17 @@ python tools/pmc_summary_csv.py $O/fetch/fetch_counter_collection.csv $O/write/w
 cp $O/bench.json profiles/r03_bench.json
 cp $O/bench_single.json profiles/r03_bench_single_stream.json
 cp $O/bench_collective.json profiles/r03_bench_collective.json
-cp $O/cfg3_roofline.json profiles/r03_cfg3_roofline.json
+python tools/pmc_summary_csv.py $O/cfg3_fetch/fetch_counter_collection.csv $O/cfg3_write/write_counter_collection.csv profiles/r03_cfg3_pmc_hbm.json > /dev/null
+python - <<'PY'
+import json
+r = json.load(open('gpurun_out/r03/cfg3_roofline.json'))
+h = json.load(open('profiles/r03_cfg3_pmc_hbm.json'))['k_stage2<256, 0>']
+r['traffic'] = h['hbm_bytes_per_launch']
+r['traffic_note'] = ('HBM bytes per launch of k_stage2<256, 0> at B = 2048 from two counter passes (FETCH_SIZE doubled as on gfx950, '
+                     'WRITE_SIZE; profiles/r03_cfg3_pmc_hbm.json); algorithmic bytes per launch of this kernel: the A rows of 2048 candidates '
+                     '(2048 * 50 * 1024 * 8 = 839 MB) read twice, for the moments and for Z = M11 A after the solve, and Z written once: 2.52 GB')
+json.dump(r, open('profiles/r03_cfg3_roofline.json', 'w'), indent=1)
+PY
 F='amdgpu.ids\|rocprofv3\|output_stream\|tool.cpp'
 grep -v "$F" $O/cfg3.log > profiles/r03_cfg3.log
 grep -v "$F" $O/hess3.log > profiles/r03_hess_cfg3.log
