@@ -40,6 +40,7 @@ SIGNATURES = {
     'oei_get_stage_times': (ctypes.c_int, [vp, vp]),
     'oei_get_solver_kernel_time': (ctypes.c_int, [vp, vp]),
     'oei_set_pipelining': (ctypes.c_int, [vp, ctypes.c_int]),
+    'oei_set_z_free': (ctypes.c_int, [vp, ctypes.c_int]),
     'oei_argmin': (ctypes.c_int, [ctypes.c_int, vp, ctypes.c_longlong, vp, vp, vp]),
     'oei_best_record': (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_longlong, vp, vp]),
     'oei_select_record': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, vp, vp, vp]),

@@ -319,6 +319,60 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     }
 }
 
+// The same product for the 256-thread kernels (q <= 64) on the matrix pipe: a wave takes 16 columns
+// of the A rows at a time (lane (li, kg) loads A[4 s + kg][16 c + li], 128 contiguous bytes per row
+// and instruction, the next column group's loads issued before this one's matrix instructions),
+// the left operand -N comes from LDS, and the 16-column tile of Z is stored the way it was loaded.
+// KS = number of k steps (4 KS >= q), a template parameter for straight-line code.
+template <int T, int KS>
+__device__ __forceinline__ void zmat_wide_mfma(const SdpWork w, int npad, size_t a_row_stride,
+                                               const double* __restrict__ Arows, double* __restrict__ Zrows) {
+    constexpr int NRT = (KS + 3) / 4, NW = T / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int q = w.q, LD = w.LD, ng = npad / 16;
+    const double* brow[KS];
+    bool bin[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int b = 4 * s + kg;
+        bin[s] = b < q;
+        brow[s] = Arows + (size_t)(bin[s] ? b : 0) * a_row_stride + li;
+    }
+    double cur[KS], nxt[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cur[s] = brow[s][16 * min(wave, ng - 1)];
+    for (int c = wave; c < ng; c += NW) {
+        const int cn = 16 * min(c + NW, ng - 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) nxt[s] = brow[s][cn];
+        double4_t acc[NRT];
+#pragma unroll
+        for (int I = 0; I < NRT; ++I) acc[I] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int b = 4 * s + kg;
+            const double bv = bin[s] ? cur[s] : 0.0;
+#pragma unroll
+            for (int I = 0; I < NRT; ++I) {
+                const int a = 16 * I + li;
+                const bool in = a < q && bin[s];
+                const double h = w.H[(in ? a : 0) * LD + (in ? b : 0)];
+                acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? -h : 0.0, bv, acc[I], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int I = 0; I < NRT; ++I)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int a = 16 * I + kg + 4 * g;
+                if (a < q) Zrows[(size_t)a * npad + 16 * c + li] = acc[I][g];
+            }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+    }
+}
+
 // ---- stage 2: moments -> SDP -> value, p, M11, Z = M11 A ------------------------------------------
 template <int T, int Q>
 __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, double noise, double fmin, int n,
@@ -365,7 +419,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
         if (tid == 0) { value[b] = NAN; status[b] = 2; }
         for (int e = tid; e < q; e += T) p_out[(size_t)b * q + e] = NAN;
         for (int e = tid; e < q * q; e += T) M11_out[(size_t)b * q * q + e] = NAN;
-        for (int e = tid; e < q * npad; e += T) Zrows[e] = NAN;
+        if (Z) for (int e = tid; e < q * npad; e += T) Zrows[e] = NAN;
         return;
     }
 #ifdef OEI_SDP_TIMING
@@ -381,25 +435,15 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
         const int i = e / q, j = e - i * q;
         M11_out[(size_t)b * q * q + e] = -w.H[i * LD + j];
     }
-    // Z[a, k] = sum_b M11[a, b] A[b, k] with M11 = -N (w.H)
-    if constexpr (Q > 0) {
+    // Z[a, k] = sum_b M11[a, b] A[b, k] with M11 = -N (w.H); without a Z buffer the second GEMM applies M11 itself
+    if (!Z) {
+    } else if constexpr (Q > 0) {
         zmat_mfma<Q>(w, npad, a_row_stride, Arows, Zrows);
     } else {
-        const int nchunks = npad / CH;
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();
-            for (int e = tid; e < q * CH; e += T) {
-                const int a = e / CH, k = e - a * CH;
-                Ac[a * (CH + 1) + k] = Arows[(size_t)a * a_row_stride + c * CH + k];
-            }
-            __syncthreads();
-            for (int e = tid; e < q * CH; e += T) {
-                const int a = e / CH, k = e - a * CH;
-                double s = 0.0;
-                for (int bb = 0; bb < q; ++bb) s -= w.H[a * LD + bb] * Ac[bb * (CH + 1) + k];
-                Zrows[(size_t)a * npad + c * CH + k] = s;
-            }
-        }
+        __syncthreads();                               // N (w.H) is complete
+        if (q <= 40) zmat_wide_mfma<T, 10>(w, npad, a_row_stride, Arows, Zrows);
+        else if (q <= 52) zmat_wide_mfma<T, 13>(w, npad, a_row_stride, Arows, Zrows);
+        else zmat_wide_mfma<T, 16>(w, npad, a_row_stride, Arows, Zrows);
     }
 #ifdef OEI_SDP_TIMING
     // diagnostic build: cycles of [moments, solve, primal, outputs + Z] and the solver's own
@@ -821,16 +865,18 @@ static int value_grad_run(oei_model* m, int B, int q, const double* X, double* v
         oei_set_error("value_grad_batched: q=%d d=%d exceeds the per-thread accumulator budget", q, d);
         return OEI_ERR_ARG;
     }
-    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, ws0, st, start_in, start_out, iters,
+    const bool zfree = m->zfree && d + 1 <= OEI_GG_MAX_DP;
+    rc = oei_launch_stage2(m, B, q, X, ws1, (size_t)q * m->npad, (size_t)m->npad, value, status, p_buf, M11_buf, zfree ? nullptr : ws0, st, start_in, start_out, iters,
                            prof ? m->kev[0] : nullptr, prof ? m->kev[1] : nullptr);
     if (rc) return rc;
-    if (rows_pad > rows)   // rows of Z beyond the batch feed the GEMM: keep them finite
+    if (rows_pad > rows && !zfree)   // rows of Z beyond the batch feed the GEMM: keep them finite
         OEI_HIP_CHECK(hipMemsetAsync(ws0 + rows * (size_t)m->npad, 0, (rows_pad - rows) * (size_t)m->npad * sizeof(double), st));
     if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[3], st));
     if (d + 1 <= OEI_GG_MAX_DP) {
         // W = Z L^-1 contracted with K1 and X inside the GEMM; a small per-candidate kernel finishes
         double* Gpart = M11_buf + (size_t)B * q * q;
-        rc = oei_launch_gemm_grad(m, ws0, ws2, p_buf, Gpart, rows, rows_pad, st);
+        rc = zfree ? oei_launch_gemm_grad_zfree(m, ws1, ws2, p_buf, M11_buf, Gpart, rows, rows_pad, q, st)
+                   : oei_launch_gemm_grad(m, ws0, ws2, p_buf, Gpart, rows, rows_pad, st);
         if (rc) return rc;
         if (prof) OEI_HIP_CHECK(hipEventRecord(m->ev[4], st));
         const size_t ldsf = ((size_t)2 * q * d + 2 * (size_t)q * q + (size_t)q * (d + 1)) * sizeof(double);
@@ -929,6 +975,12 @@ static int value_grad_auto(oei_model* m, int B, int q, const double* X, double* 
         return value_grad_pipelined(m, B, q, X, value, grad, status, flags, st, m->ws0, m->ws1, m->ws2, m->aux,
                                     m->pipeline > 1 ? m->pipeline : 2, 2, start_in, start_out, iters);
     return value_grad_run(m, B, q, X, value, grad, status, flags, st, m->ws0, m->ws1, m->ws2, m->aux, start_in, start_out, iters);
+}
+
+extern "C" int oei_set_z_free(oei_model* m, int on) {
+    if (!m) { oei_set_error("set_z_free: null model"); return OEI_ERR_ARG; }
+    m->zfree = on ? 1 : 0;
+    return OEI_OK;
 }
 
 extern "C" int oei_set_pipelining(oei_model* m, int on) {

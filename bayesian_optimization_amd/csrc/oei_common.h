@@ -72,6 +72,7 @@ struct oei_model {
     hipStream_t side[2];
     hipEvent_t ev_fork, ev_join[2];
     int pipeline;     // large value+gradient batches run as two halves on the side streams
+    int zfree;        // second GEMM on the A rows with M11 applied in its epilogue: no Z buffer (oei_set_z_free)
     int n_cu;         // compute units of the device
 };
 
@@ -163,6 +164,9 @@ int oei_launch_gram_blk(const double* E, double* G, int B, int RP, int npad, hip
 #define OEI_GG_MAX_DP 12
 int oei_launch_gemm_grad(const oei_model* m, const double* Z, const double* K1, const double* pvec,
                          double* Gpart, size_t nrows, size_t rows_pad, hipStream_t st);
+int oei_launch_gemm_grad_zfree(const oei_model* m, const double* A, const double* K1, const double* pvec,
+                               const double* M11, double* Gpart, size_t nrows, size_t rows_pad, int q,
+                               hipStream_t st);
 int oei_launch_gemm_nt(const double* A, const double* Bm, double* C, size_t rows_pad, int npad,
                        int lower, hipStream_t st);
 

@@ -267,10 +267,12 @@ template <int NH, int TRI, bool SWAP = false, bool DBUF = true>
 __device__ __forceinline__ void gemm_tile_acc(const double* __restrict__ Ag0,
                                               const double* __restrict__ Bg0, int ld, int kbeg,
                                               int kend, double* As, double* Bs,
-                                              double4_t (&acc)[NH][4]) {
+                                              double4_t (&acc)[NH][4], int arows = 1 << 30) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int srow = tid >> 2, scol = (tid & 3) * 4;        // staging: thread t moves 4 consecutive doubles of row t / 4
-    const double* Ag = Ag0 + (size_t)srow * ld + scol;
+    // arows: rows of the A panel that exist (NH = 1 callers whose panel may run past the buffer:
+    // the rows behind it repeat the last one and their results are never stored)
+    const double* Ag = Ag0 + (size_t)(srow < arows ? srow : arows - 1) * ld + scol;
     const double* Bg = Bg0 + (size_t)srow * ld + scol;
 #pragma unroll
     for (int h = 0; h < NH; ++h)
@@ -542,6 +544,146 @@ __global__ __launch_bounds__(256, NH == 1 ? 3 : 2) void k_gemm_grad(const double
         }
     }
   }
+}
+
+// The same kernel without Z = M11 A: the product runs on the A rows themselves (V = A L^-1 does not
+// depend on the SDP solution) and M11 is applied to the tile before the contraction, W = M11 V per
+// candidate, so that Z is neither written by the solver kernel nor read here.  A tile holds whole
+// candidates (64 / q of them, q <= 64; the rows behind them are ignored).  After the K loop the
+// 64 x 64 tile of V goes through LDS (in place of the operand panels); wave w then forms the rows
+// 16 w .. 16 w + 15 of W on the matrix pipe as W^T = V_c^T M11^T over the rows of the candidates its
+// 16 rows belong to: the left operand is V read from LDS with the same column permutation as the
+// swapped K loop (lane li supplies column 4 (li & 3) + (li >> 2) of a 16-column group), the right
+// operand the lane's row of the block-diagonal M11 (LDS, zero outside the row's own candidate), and
+// the accumulators come out in the layout the contraction expects: accumulator g of lane (li, kg)
+// = W[row li][column 4 kg + g].
+// Dynamic LDS: the tile's M11 rows, 64 x (q | 1) doubles.
+template <int DPM>
+__global__ __launch_bounds__(256, 3) void k_gemm_grad_zfree(const double* __restrict__ A,
+                                                   const double* __restrict__ LinvT,
+                                                   const double* __restrict__ K1,
+                                                   const double* __restrict__ alpha,
+                                                   const double* __restrict__ Xtrain,
+                                                   const double* __restrict__ pvec,
+                                                   const double* __restrict__ M11,
+                                                   double* __restrict__ Gpart, int npad, int d, int q,
+                                                   unsigned nrb, size_t nrows, size_t arows) {
+    constexpr int VLD = 66;
+    static_assert(2 * GM_BM * GM_LDS + 2 * GM_BN * GM_LDS >= 64 * VLD, "the V tile reuses the operand panels");
+    __shared__ __attribute__((aligned(16))) double Pan[2 * GM_BM * GM_LDS + 2 * GM_BN * GM_LDS];
+    __shared__ double Xs[64 * (DPM + 1)];
+    extern __shared__ __attribute__((aligned(16))) double Ms[];       // [64][q | 1]
+    double* As = Pan;
+    double* Bs = Pan + 2 * GM_BM * GM_LDS;
+    const int nt = npad / GM_BN, nch = nt / 2 + 1, dp = d + 1;
+    const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const size_t rb = (size_t)(slot / nch) * 8 + xcd;
+    if (rb >= nrb) return;
+    int tiles[2];
+    const int ntile = gemm_chain_tiles((int)(slot % nch), nt, 0, tiles);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int cpt = 64 / q, live = cpt * q, mld = q | 1;
+    const size_t r0 = rb * (size_t)live;
+    // the tile's rows of M11 (block diagonal: row r of the tile meets the q columns of its own candidate)
+    for (int e = tid; e < live * q; e += 256) {
+        const int r = e / q, c = e - r * q;
+        const size_t rg = r0 + r;
+        Ms[r * mld + c] = rg < nrows ? M11[rg * q + c] : 0.0;       // M11 is [B][q][q]: row rg = b q + a
+    }
+    // this wave's rows 16 w .. 16 w + 15 and the candidates they belong to
+    const int row = 16 * wave + li;
+    const bool rowin = row < live && r0 + row < nrows;
+    const int cand = (rowin ? row : 0) / q, cbase = cand * q;
+    const int c_lo = (16 * wave) / q, c_hi = min(cpt - 1, (16 * wave + 15) / q);
+    const int klo = c_lo * q, khi = (c_hi + 1) * q;                   // uniform; empty for a wave past the live rows
+    const int ks = khi > klo ? (khi - klo + 3) >> 2 : 0;
+    const int pcol = 4 * (li & 3) + (li >> 2);
+  for (int it = 0; it < ntile; ++it) {
+    const unsigned split = (unsigned)tiles[it];
+    const int j0 = (int)split * GM_BN;
+    __syncthreads();                                 // the previous tile's readers of Xs and V are done; Ms is published
+    for (int e = tid; e < 64 * dp; e += 256) {
+        const int k = e / dp, l = e - k * dp;
+        Xs[k * (DPM + 1) + l] = (l < d) ? Xtrain[(size_t)(j0 + k) * d + l] : 1.0;
+    }
+    double4_t acc[1][4];
+    const size_t left = arows - r0;
+    gemm_tile_acc<1, 2, true, true>(A + r0 * npad, LinvT + (size_t)j0 * npad, npad, j0, npad, As, Bs, acc,
+                                    left < 64 ? (int)left : 64);
+    __syncthreads();                                 // every wave has read its last fragments of the panels
+    double* Vs = Pan;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Vs[row * VLD + 16 * t + 4 * kg + g] = acc[0][t][g];
+    __syncthreads();
+    double4_t wacc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wacc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < ks; ++s) {
+        const int rp = klo + 4 * s + kg;             // row of the tile = k position of this step
+        const bool on = rowin && rp >= cbase && rp < cbase + q;
+        const double mv = Ms[row * mld + (on ? rp - cbase : 0)];
+        const double* vrow = Vs + (rp < 64 ? rp : 63) * VLD + pcol;
+        double vv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vv[t] = vrow[16 * t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            wacc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rp < khi ? vv[t] : 0.0, on ? mv : 0.0, wacc[t], 0, 0, 0);
+    }
+    // contraction with K1 and X as in k_gemm_grad (Xs was published by the barriers above)
+    const double* alp = alpha + j0 + 4 * kg;
+    const bool lin = li < dp;
+    const double* xl = Xs + (size_t)(4 * kg) * (DPM + 1) + (lin ? li : 0);
+    {
+        const size_t rg = r0 + wave * 16;                     // first row of this 16-row group
+        const size_t r = rg + li;
+        const size_t rc = rowin ? r : (r0 < nrows ? r0 : nrows - 1);   // rows past the live ones read a valid row, never stored
+        const double pr = pvec[rc];
+        const double* k1row = K1 + rc * npad + j0 + 4 * kg;
+        double4_t cacc = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double2 ka = *reinterpret_cast<const double2*>(k1row + 16 * t);
+            const double2 kb = *reinterpret_cast<const double2*>(k1row + 16 * t + 2);
+            const double k1v[4] = {ka.x, ka.y, kb.x, kb.y};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double ck = fma(pr, alp[16 * t + g], -2.0 * wacc[t][g]) * k1v[g];
+                const double xv = xl[(16 * t + g) * (DPM + 1)];
+                cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(ck, lin ? xv : 0.0, cacc, 0, 0, 0);
+            }
+        }
+        // cacc[g] = Gacc[row rg + kg + 4 g][l = li]
+        if (lin) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rt = wave * 16 + kg + 4 * g;
+                const size_t ro = r0 + rt;
+                if (rt < live && ro < nrows) Gpart[((size_t)split * nrows + ro) * dp + li] = cacc[g];
+            }
+        }
+    }
+  }
+}
+
+int oei_launch_gemm_grad_zfree(const oei_model* m, const double* A, const double* K1, const double* pvec,
+                               const double* M11, double* Gpart, size_t nrows, size_t rows_pad, int q,
+                               hipStream_t st) {
+    const unsigned nt = (unsigned)(m->npad / GM_BN);
+    if (m->d + 1 > 12 || q > 64) return OEI_ERR_ARG;
+    const int live = (64 / q) * q;
+    const unsigned nrb = (unsigned)((nrows + live - 1) / live);
+    const size_t lds = (size_t)64 * (q | 1) * sizeof(double);
+    dim3 grid(((nrb + 7) / 8) * 8 * (nt / 2 + 1));
+    if (m->d + 1 <= 8)
+        hipLaunchKernelGGL((k_gemm_grad_zfree<8>), grid, dim3(256), lds, st, A, m->LinvT, K1, m->alpha, m->X, pvec, M11, Gpart, m->npad, m->d, q, nrb, nrows, rows_pad);
+    else
+        hipLaunchKernelGGL((k_gemm_grad_zfree<12>), grid, dim3(256), lds, st, A, m->LinvT, K1, m->alpha, m->X, pvec, M11, Gpart, m->npad, m->d, q, nrb, nrows, rows_pad);
+    OEI_HIP_CHECK(hipGetLastError());
+    return OEI_OK;
 }
 
 // Gpart [npad / 64][nrows][d+1]; returns OEI_ERR_ARG when d + 1 exceeds the register budget of the

@@ -152,6 +152,7 @@ extern "C" int oei_model_create(oei_model** out, int n, int d, const double* X_t
     if (rc) { delete m; return rc; }
     if (hipGetDevice(&m->device) != hipSuccess) { delete m; oei_set_error("model_create: hipGetDevice failed"); return OEI_ERR_HIP; }
     m->pipeline = 1;
+    m->zfree = 0;
     if (hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device) != hipSuccess) m->n_cu = 0;
     if (m->device < 64) {       // set-up of the allocation-free entry point for this device
         const int src = oei_noalloc_setup_device(m->device);

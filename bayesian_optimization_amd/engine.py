@@ -102,6 +102,11 @@ class DeviceGP:
         integer n >= 2 forces n pieces at any batch size, for measurements)."""
         check(lib.oei_set_pipelining(self._h, int(on)), 'oei_set_pipelining')
 
+    def set_z_free(self, on):
+        """Second GEMM on the A rows with M11 applied in its epilogue instead of Z = M11 A from the
+        solver kernel (default off)."""
+        check(lib.oei_set_z_free(self._h, int(bool(on))), 'oei_set_z_free')
+
     def stage_times_ms(self):
         """Durations (ms) of [gram, GEMM1, moments+SDP, GEMM2, gradient] of the last profiled call."""
         ms = (ctypes.c_float * 5)()

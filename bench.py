@@ -153,6 +153,8 @@ def main():
     ap.add_argument('--single-stream', action='store_true',
                     help='keep every launch of a step on one stream (kernel-trace profiles of whole-batch launches); '
                          'by default batches of two solver rounds and more run as two halves on two internal streams')
+    ap.add_argument('--z-free', action='store_true',
+                    help='measurement: second GEMM on the A rows with M11 applied in its epilogue (no Z buffer); off by default')
     ap.add_argument('--backend', default='nccl', help="process-group backend; 'gloo' only for rehearsing N > 1 on one GPU or on the CPU")
     ap.add_argument('--one-device', action='store_true', help='rehearsal: every rank uses GPU 0')
     ap.add_argument('--force-collective', action='store_true',
@@ -225,6 +227,8 @@ def main():
                       model.kernel.lengthscales, model.noise, floor_mode=model.kernel.floor_mode)
         if args.single_stream:
             gp.set_pipelining(False)
+        if args.z_free:
+            gp.set_z_free(True)
 
         def step():
             return multistart.evaluate_and_select(gp, X_local, index_base=lo, force_collective=args.force_collective)

@@ -185,6 +185,14 @@ int oei_get_solver_kernel_time(oei_model* m, float* ms);
  * capture, since the first pipelined call creates the streams).  `on` = 1 selects the rule above;
  * a value n >= 2 is a diagnostic: n pieces, alternating between the two streams, at any batch size. */
 int oei_set_pipelining(oei_model* m, int on);
+/* No counterpart in the reference.  With `on` != 0 the value + gradient entry points skip the
+ * per-candidate product Z = M11 A in the solver kernel: the second matrix product runs on the A rows
+ * (A L^-1 does not depend on the SDP solution) and M11 is applied to every 64 x 64 tile before the
+ * gradient contraction, so Z is neither written nor read (420 MB less HBM traffic at q = 20,
+ * n = 310, B = 4096 for 15 % more matrix instructions in that product).  Same results up to the
+ * order of the sums.  Off by default (measured no faster at that shape); d <= 11 only, otherwise
+ * ignored. */
+int oei_set_z_free(oei_model* m, int on);
 
 /* ---- hyper-parameter objective ------------------------------------------------------------------
  * Negative log marginal likelihood of the GP behind the handle and its gradient, the objective of

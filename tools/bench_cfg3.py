@@ -20,6 +20,8 @@ q, d, n = 50, 10, 1000
 model = hart6.make_model(n, d=d, lengthscale=0.8)
 gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.8], 1e-6, floor_mode=1)
 gp.set_profiling(True)
+if '--z-free' in sys.argv:          # measurement: second GEMM on the A rows, no Z buffer
+    gp.set_z_free(True)
 out = {}
 # --only-2048: the counter passes, where every launch of a kernel should be the same size
 for B in ((2048,) if '--only-2048' in sys.argv else (64, 512, 2048)):
