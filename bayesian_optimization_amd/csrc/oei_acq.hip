@@ -212,6 +212,104 @@ __device__ __forceinline__ void posterior_moments_mfma(const SdpWork w, const Ke
 #endif
 }
 
+// The same for the 256-thread kernels (32 < q <= 64, NR = row tiles of E: 3, 4 or 5): the waves
+// share the columns (wave w takes the 16-column groups w, w + 4, ...: no row is loaded twice and
+// the matrix work is even), every wave keeps a partial E E^T in its accumulators, and the four
+// partials are added through w.S / mu one wave after the other (a fixed order, so the sums carry
+// the same bits in every run).  It replaced a loop over LDS-staged chunks of the A rows on the
+// vector unit (2.6 M multiply-adds per candidate at q = 50, LDS-bound: a fifth of the kernel).
+template <int T, int NR>
+__device__ __forceinline__ void posterior_moments_mfma_wide(const SdpWork w, const KernParams& kp, double noise,
+                                                            int npad, size_t astride,
+                                                            const double* __restrict__ Arows,
+                                                            const double* __restrict__ v,
+                                                            const lds_f64* xq, lds_f64* mu) {
+    constexpr int NTILE = NR * (NR + 1) / 2, NW = T / 64, PF = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = w.q, LD = w.LD, d = kp.d;
+    const int li = lane & 15, kg = lane >> 4;
+    const double* src[NR];
+#pragma unroll
+    for (int I = 0; I < NR; ++I) {
+        const int r = 16 * I + li;
+        // rows past q read v as well: their products only reach entries of E E^T that nothing reads
+        src[I] = (r < q ? Arows + (size_t)r * astride : v) + 4 * kg;
+    }
+    double4_t acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int ns = npad / 16, nsw = ns / NW;          // npad is a multiple of 64: every wave has nsw groups
+    double4_t ring[PF][NR];
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int I = 0; I < NR; ++I)
+            ring[u][I] = *reinterpret_cast<const double4_t*>(src[I] + 16 * (wave + NW * min(u, nsw - 1)));
+    for (int s0 = 0; s0 < nsw; s0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            double4_t cur[NR];
+#pragma unroll
+            for (int I = 0; I < NR; ++I) cur[I] = ring[u][I];
+            const int sn = min(s0 + u + PF, nsw - 1);
+#pragma unroll
+            for (int I = 0; I < NR; ++I)
+                ring[u][I] = *reinterpret_cast<const double4_t*>(src[I] + 16 * (wave + NW * sn));
+            if (s0 + u < nsw) {
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    int t = 0;
+#pragma unroll
+                    for (int I = 0; I < NR; ++I)
+#pragma unroll
+                        for (int J = 0; J <= I; ++J, ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][v4], cur[J][v4], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // accumulator g of lane l is entry (row (l >> 4) + 4 g, column l & 15) of its tile
+    for (int r = 0; r < NW; ++r) {
+        if (wave == r) {
+            int t = 0;
+#pragma unroll
+            for (int I = 0; I < NR; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J, ++t)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int i = 16 * I + kg + 4 * g, j = 16 * J + li;
+                        if (i < q && j <= i) w.S[i * LD + j] = (r ? w.S[i * LD + j] : 0.0) + acc[t][g];
+                        else if (i == q && j < q) mu[j] = (r ? mu[j] : 0.0) + acc[t][g];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < q * (q + 1) / 2; e += T) {        // lower triangle only: a kernel evaluation per entry
+        int i, j;
+        sdp_tri_index(e, i, j);
+        double t = 0.0;
+        for (int l = 0; l < d; ++l) {
+            const double df = xq[i * d + l] - xq[j * d + l];
+            t += df * df * kp.inv_ls2[l];
+        }
+        double k0, k1, k2;
+        kappa_eval<0>(kp.kind, kp.floor_mode, t, k0, k1, k2);
+        const double val = kp.variance * k0 - w.S[i * LD + j] + (i == j ? noise : 0.0);
+        w.S[i * LD + j] = val;
+        w.S[j * LD + i] = val;
+    }
+    __syncthreads();
+}
+template <int T>
+__device__ __forceinline__ void posterior_moments_wide(const SdpWork w, const KernParams& kp, double noise,
+                                                       int npad, size_t astride, const double* __restrict__ Arows,
+                                                       const double* __restrict__ v, const lds_f64* xq, lds_f64* mu) {
+    if (w.q < 48) posterior_moments_mfma_wide<T, 3>(w, kp, noise, npad, astride, Arows, v, xq, mu);
+    else if (w.q < 64) posterior_moments_mfma_wide<T, 4>(w, kp, noise, npad, astride, Arows, v, xq, mu);
+    else posterior_moments_mfma_wide<T, 5>(w, kp, noise, npad, astride, Arows, v, xq, mu);
+}
+
 // Z[a, k] = -sum_b N[a][b] A[b][k] for the one-wave kernels, on the matrix pipe: N (w.H) is the
 // left operand, held in registers for the whole pass; each 16-column tile of the candidate's A
 // rows is loaded once (128 B per row and load instruction) and its Z tile stored the same way.
@@ -306,7 +404,7 @@ __global__ __launch_bounds__(T) void k_omega(KernParams kp, double noise, int n,
     for (int e = tid; e < q * kp.d; e += T) xq[e] = Xq[(size_t)b * q * kp.d + e];
     __syncthreads();
     if constexpr (Q > 0) posterior_moments_mfma<Q>(w, kp, noise, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu);
-    else posterior_moments<T>(w, kp, noise, n, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu, Ac, vc);
+    else posterior_moments_wide<T>(w, kp, noise, npad, (size_t)npad, A + (size_t)b * q * npad, v, xq, mu);
     double* om = omega + (size_t)b * k_ * k_;
     for (int e = tid; e < k_ * k_; e += T) {
         const int i = e / k_, j = e - i * k_;
@@ -403,7 +501,7 @@ __global__ __launch_bounds__(T, SDP_MIN_WAVES(Q)) void k_stage2(KernParams kp, d
     const long long tk0 = clock64();
 #endif
     if constexpr (Q > 0) posterior_moments_mfma<Q>(w, kp, noise, npad, a_row_stride, Arows, v, xq, mu);
-    else posterior_moments<T>(w, kp, noise, n, npad, a_row_stride, Arows, v, xq, mu, Ac, vc);
+    else posterior_moments_wide<T>(w, kp, noise, npad, a_row_stride, Arows, v, xq, mu);
 #ifdef OEI_SDP_TIMING
     const long long tk1 = clock64();
 #endif
