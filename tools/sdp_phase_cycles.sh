@@ -12,3 +12,4 @@ wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/liboei_timing.so $D/*.o
 OEI_LIB_OVERRIDE=$D/liboei_timing.so python tools/sdp_phase_cycles.py "$1" "$2"
 if [ "$1" = 20 ]; then OEI_LIB_OVERRIDE=$D/liboei_timing.so python tools/stage2_phase_cycles.py "$2"; fi
+if [ "$1" = 50 ]; then OEI_LIB_OVERRIDE=$D/liboei_timing.so python tools/stage2_phase_cycles.py "$2" cfg3; fi

@@ -1,15 +1,21 @@
 """Diagnostic (timing build only, see tools/sdp_phase_cycles.sh): cycles one wave of k_stage2 spends in
-the posterior moments, the SDP solve, the primal matrix and the outputs + Z, at the benchmark's shape."""
+the posterior moments, the SDP solve, the primal matrix and the outputs + Z, at the benchmark's shape
+(or, with a second argument `cfg3`, one workgroup of the wide kernel at q = 50, d = 10, n = 1000)."""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesian_optimization_amd import DeviceGP
 from oracle import hart6, gp as ogp
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-model = hart6.make_model(310)
-gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+if len(sys.argv) > 2 and sys.argv[2] == 'cfg3':          # the largest shape: q = 50, d = 10, n = 1000 (wide path)
+    model = hart6.make_model(1000, d=10, lengthscale=0.8)
+    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.8], 1e-6, floor_mode=1)
+    X = np.random.RandomState(2).uniform(-.5, .5, (B, 50, 10))
+else:
+    model = hart6.make_model(310)
+    gp = DeviceGP(model.X, model.y, ogp.KERNEL_MATERN32, 1.0, [0.5], 1e-6, floor_mode=1)
+    X = np.random.RandomState(1).uniform(-.5, .5, (B, 20, 6))
 gp.set_pipelining(False)
-X = np.random.RandomState(1).uniform(-.5, .5, (B, 20, 6))
 for _ in range(3):
     out = gp.value_grad_warm(X)
 c = out[4].cpu().numpy()
