@@ -36,5 +36,13 @@ timeout -k 10 400 bash tools/hess_wide_phase_cycles.sh 256 > $O/hess_wide_phase_
 # do fp64 matrix and vector instructions of two waves on one SIMD overlap?
 hipcc -O3 --offload-arch=gfx950 -o /tmp/mixed_pipes tools/micro/mixed_pipes.hip > $O/micro_build.log 2>&1 || exit 1
 timeout -k 10 60 /tmp/mixed_pipes > $O/micro_mixed_pipes.log 2>&1 || exit 1
+# cycles of one q x q x q product of LDS matrices by four waves (the wide Hessian kernel's products)
+hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -amdgpu-mfma-vgpr-form -mllvm -pragma-unroll-threshold=1000000 -I bayesian_optimization_amd/csrc -I include -o /tmp/mm_lds tools/micro/mm_lds.hip >> $O/micro_build.log 2>&1 || exit 1
+(timeout -k 10 60 /tmp/mm_lds 50 && timeout -k 10 60 /tmp/mm_lds 64) > $O/micro_mm_lds.log 2>&1 || exit 1
+# the variant without the Z buffer
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE -d $O/zfree_fetch -o fetch --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --z-free --steps 5 --warmup 1 > $O/zfree_fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE -d $O/zfree_write -o write --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --z-free --steps 5 --warmup 1 > $O/zfree_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/zfree_stats -o stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-hessian --single-stream --z-free > $O/zfree_stats.log 2>&1 || exit 1
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-hessian --z-free > $O/bench_zfree.json 2> $O/bench_zfree.err || exit 1
 timeout -k 10 200 python3 tools/warm_probe_first_order.py > $O/warm_probe_first_order.log 2>&1 || exit 1
 echo done > $O/done

@@ -34,6 +34,10 @@ grep -v "$F" $O/fit.log > profiles/r03_fit.log
 grep -v "$F" $O/phase_cycles.log > profiles/r03_phase_cycles.log
 (grep -v "$F" $O/phase_cycles_q32.log; grep -v "$F" $O/phase_cycles_q50.log) > profiles/r03_phase_cycles_q32_q50.log
 grep -v "$F" $O/hess_wide_phase_cycles.log > profiles/r03_hess_wide_phase_cycles.log
+cp $O/micro_mm_lds.log profiles/r03_micro_mm_lds.log
+python tools/pmc_summary_csv.py $O/zfree_fetch/fetch_counter_collection.csv $O/zfree_write/write_counter_collection.csv profiles/r03_zfree_pmc_hbm.json > /dev/null
+python tools/kernel_stats_csv.py $O/zfree_stats/stats_kernel_stats.csv profiles/r03_zfree_kernel_stats.csv
+cp $O/bench_zfree.json profiles/r03_bench_zfree.json
 if [ -f $O/micro_mixed_pipes.log ]; then cp $O/micro_mixed_pipes.log profiles/r03_micro_mixed_pipes.log; grep -v "$F" $O/warm_probe_first_order.log > profiles/r03_warm_probe_first_order.log; fi
 (grep -v "$F" $O/round_lbfgs.log; grep -v "$F" $O/round_newton.log) > profiles/r03_round.log
 (grep "^pass" $O/bo_loop_lbfgs.log | sed 's/^/--nl_solver=lockstep (default) --hessian=0: /'; grep "^pass" $O/bo_loop_newton.log | sed 's/^/--nl_solver=lockstep-newton: /') > profiles/r03_bo_loop.log
