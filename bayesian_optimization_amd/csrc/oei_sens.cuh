@@ -195,13 +195,96 @@ __device__ __forceinline__ void wave_mm_mfma(int lane, int q, int LD, const lds_
             }
 }
 
+// The 2 x 2 tiles of a wave that has its SIMD to itself or shares it with one other wave (the
+// 256-thread kernels): a wave issues in order, so the index arithmetic and LDS reads of a step (about
+// 40 instructions in wave_mm_mfma) and its four matrix instructions take turns -- a q = 50 product
+// took 7.1 k cycles for 3.3 k cycles of matrix instructions (tools/micro/mm_lds.hip).  Here the
+// lane's operand pointers advance by a constant per step, rows and columns past q carry no masks
+// (they read row / column 0 and only reach entries of C that are not stored), the next step's reads
+// are issued before this step's matrix instructions, and the partial last step (q not a multiple of
+// four) is peeled: 5.0 k cycles.
+template <bool TA, bool TB, bool SC>
+__device__ __forceinline__ void wave_mm_mfma_lean(int lane, int q, int LD, const lds_f64* A, const lds_f64* B,
+                                                  lds_f64* C, const lds_f64* sc, int I0, int J0) {
+    const int li = lane & 15, kg = lane >> 4;
+    sens_double4 acc[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) acc[I][J] = (sens_double4){0.0, 0.0, 0.0, 0.0};
+    const lds_f64* pa[2];
+    const lds_f64* pb[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        const int i = 16 * (I0 + I) + li, j = 16 * (J0 + I) + li;
+        const int ic = i < q ? i : 0, jc = j < q ? j : 0;
+        pa[I] = A + (TA ? kg * LD + ic : ic * LD + kg);
+        pb[I] = B + (TB ? jc * LD + kg : kg * LD + jc);
+    }
+    const lds_f64* ps = SC ? sc + kg : nullptr;
+    const int sa = TA ? 4 * LD : 4, sb = TB ? 4 : 4 * LD;
+    const int ksf = q >> 2;                                  // steps whose four k positions all lie inside q
+    double av[2], bv[2], an[2], bn[2];
+    {
+        const double s0 = SC ? ps[0] : 1.0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) { const double x = pa[I][0]; av[I] = SC ? x * s0 : x; bv[I] = pb[I][0]; }
+    }
+    for (int s = 0; s < ksf; ++s) {
+        const bool more = s + 1 < ksf;
+        if (SC) ps += more ? 4 : 0;
+        const double sn = SC ? ps[0] : 1.0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            pa[I] += more ? sa : 0; pb[I] += more ? sb : 0;
+            const double x = pa[I][0];
+            an[I] = SC ? x * sn : x; bn[I] = pb[I][0];
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[I][J], 0, 0, 0);
+#pragma unroll
+        for (int I = 0; I < 2; ++I) { av[I] = an[I]; bv[I] = bn[I]; }
+    }
+    if (q & 3) {
+        const int k = 4 * ksf + kg;
+        const bool kin = k < q;
+        const int kc = kin ? k : 0;
+        const double s0 = SC ? sc[kc] : 1.0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            const int i = 16 * (I0 + I) + li, j = 16 * (J0 + I) + li;
+            const int ic = i < q ? i : 0, jc = j < q ? j : 0;
+            const double x = A[TA ? kc * LD + ic : ic * LD + kc], y = B[TB ? jc * LD + kc : kc * LD + jc];
+            av[I] = kin ? (SC ? x * s0 : x) : 0.0;
+            bv[I] = kin ? y : 0.0;
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[I][J], 0, 0, 0);
+    }
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 16 * (I0 + I) + kg + 4 * g, j = 16 * (J0 + J) + li;
+                if (i < q && j < q) C[i * LD + j] = acc[I][J][g];
+            }
+}
+
 // The product for a 256-thread workgroup and q <= 64 on the matrix pipe: wave w computes the
 // 32 x 32 block (w >> 1, w & 1) of C; a block that lies past q altogether is skipped.
 template <bool TA, bool TB, bool SC>
 __device__ __forceinline__ void wg4_mm_mfma(int q, int LD, const lds_f64* A, const lds_f64* B, lds_f64* C,
                                             const lds_f64* sc = nullptr) {
     const int wave = threadIdx.x >> 6, I0 = 2 * (wave >> 1), J0 = 2 * (wave & 1);
-    if (16 * I0 < q && 16 * J0 < q) wave_mm_mfma<2, TA, TB, SC>(threadIdx.x & 63, q, LD, A, B, C, sc, I0, J0);
+    if (16 * I0 < q && 16 * J0 < q) wave_mm_mfma_lean<TA, TB, SC>(threadIdx.x & 63, q, LD, A, B, C, sc, I0, J0);
 }
 
 template <int T, bool WAVE, bool TA, bool TB, bool SC>
