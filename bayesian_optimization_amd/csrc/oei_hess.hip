@@ -885,8 +885,8 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
         else hess_table_transform<T, 16>(q, LD, d, w.S, DS, WVT);
     }
     __syncthreads();
-    double lr[16], lc[16];
-    sens_linv_regs(w.X, q, LD, lr, lc);
+    double lm[16];
+    sens_linv_regs(w.X, q, LD, lm);
 #ifdef OEI_HESS_TIMING
     const long long extra_cyc[4] = {t_pre1 - t_kernel0, t_pre2 - t_pre1, t_linv1 - t_state1, 0};
 #endif
@@ -915,10 +915,10 @@ __global__ __launch_bounds__(T, 2) void k_hess_wide(KernParams kp, double noise,
             wv[tid] = WVT[(size_t)tid * qd + al];
         }
 #ifdef OEI_HESS_TIMING
-        sens_direction_lean<T>(w, sv, a, wv, scl, utc, lr, lc, sens_cyc);
+        sens_direction_lean<T>(w, sv, a, wv, scl, utc, lm, sens_cyc);
         long long sens_t0 = clock64();
 #else
-        sens_direction_lean<T>(w, sv, a, wv, scl, utc, lr, lc);
+        sens_direction_lean<T>(w, sv, a, wv, scl, utc, lm);
 #endif
         {
             const int ri = tid >> 2, row = ri < q ? ri : 0;

@@ -502,30 +502,35 @@ __device__ __forceinline__ double quad_row_sum(int q, F term) {
 // (in LDS; overwritten).  Like the YFORM of sens_direction it stops at Y = U Z: out Y in w.H,
 // sv.w1 = N dc, sv.w2 = dN c = Y utc (utc = U^T c), sv.dp.
 // Needs w.ip = 1 / p, w.sq, w.rp, sv.c, sv.t1 and, in registers, the thread's share of L^-1 (L the
-// factor of -hess g): thread (row, part) = (tid >> 2, tid & 3) holds lr[j] = L^-1[row][part + 4 j]
-// and lc[j] = L^-1[part + 4 j][row], zeros past q (sens_linv_regs).  scl is [q] scratch.
+// factor of -hess g, L^-1 lower triangular): thread (row, part) = (tid >> 2, tid & 3) holds, for
+// k = part + 4 j, lm[j] = L^-1[row][k] where k <= row and L^-1[k][row] where k > row -- its pieces
+// of row `row` and of column `row` in one array, the diagonal entry serving both -- zeros past q
+// (sens_linv_regs).  scl is [q] scratch.
 // Three q x q matrices of LDS: U (w.S) and the two scratch matrices w.X and w.H.
-__device__ __forceinline__ void sens_linv_regs(const lds_f64* Li, int q, int LD, double (&lr)[16], double (&lc)[16]) {
+__device__ __forceinline__ void sens_linv_regs(const lds_f64* Li, int q, int LD, double (&lm)[16]) {
     const int ri = threadIdx.x >> 2, part = threadIdx.x & 3, row = ri < q ? ri : 0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int k = part + 4 * j, kc = k < q ? k : 0;
         const double a = Li[row * LD + kc], b = Li[kc * LD + row];
-        lr[j] = (k < q && k <= row) ? a : 0.0;
-        lc[j] = (k < q && k >= row) ? b : 0.0;
+        lm[j] = k >= q ? 0.0 : (k <= row ? a : b);
     }
 }
-// sum_k m[j(k)] x[k] over the thread's k = part, part + 4, ... and over the four threads of the row
+// sum_k m[j(k)] x[k] over the thread's k = part, part + 4, ... on one side of the diagonal (LOWER:
+// k <= row, the product with row `row` of L^-1; else k >= row, the product with its column) and
+// over the four threads of the row
+template <bool LOWER>
 __device__ __forceinline__ double quad_reg_sum(int q, const double (&m)[16], const lds_f64* x) {
-    const int part = threadIdx.x & 3;
+    const int part = threadIdx.x & 3, ri = threadIdx.x >> 2, row = ri < q ? ri : 0;
     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; j += 2) {
         if (4 * j < q) {
             const int k0 = part + 4 * j, k1 = k0 + 4;
             const double x0 = x[k0 < q ? k0 : 0], x1 = x[k1 < q ? k1 : 0];
-            acc0 = fma(m[j], x0, acc0);              // m is zero where k >= q
-            acc1 = fma(m[j + 1], x1, acc1);
+            const bool on0 = LOWER ? k0 <= row : k0 >= row, on1 = LOWER ? k1 <= row : k1 >= row;
+            acc0 = fma(on0 ? m[j] : 0.0, x0, acc0);              // m is zero where k >= q
+            acc1 = fma(on1 ? m[j + 1] : 0.0, x1, acc1);
         }
     }
     double acc = acc0 + acc1;
@@ -536,7 +541,7 @@ __device__ __forceinline__ double quad_reg_sum(int q, const double (&m)[16], con
 template <int T>
 __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensVec sv, int a_dir,
                                                     lds_f64* wv, lds_f64* scl, const lds_f64* utc,
-                                                    const double (&lr)[16], const double (&lc)[16]
+                                                    const double (&lm)[16]
 #ifdef OEI_HESS_TIMING
                                                     , long long (&sens_cyc)[12]
 #endif
@@ -585,12 +590,12 @@ __device__ __forceinline__ void sens_direction_lean(const SdpWork w, const SensV
     // matrix entries in registers.  (A substitution with L costs 2 q dependent steps in one wave,
     // each a broadcast through the scalar unit, or two barriers per component across the workgroup.)
     {
-        const double y = quad_reg_sum(q, lr, w.step);                                  // y = L^-1 rhs
+        const double y = quad_reg_sum<true>(q, lm, w.step);                                  // y = L^-1 rhs
         if (rown) sv.rd[ri] = y;
     }
     __syncthreads();
     {
-        const double x = quad_reg_sum(q, lc, sv.rd);                                   // L^-T y
+        const double x = quad_reg_sum<false>(q, lm, sv.rd);                                   // L^-T y
         if (rown) {
             const double dp = -x, ipi = w.ip[ri];
             sv.dp[ri] = dp;
