@@ -349,6 +349,104 @@ __device__ int sdp_jacobi_cols(lds_f64* Gc, int q, int LD, double tol2, double f
 template <int NR>
 __device__ int sdp_jacobi_rows4(lds_f64* Gc, int q, int LD, double tol2, double fin2, lds_f64* red);
 
+// The two q x q x q products of an evaluation for the 256-thread path on the matrix pipe:
+//   P = 1:  G[r][a] = sum_{j >= r} Lc[j][r] Vp[j][a] - gam tv[r] grad[a]      (Vp in w.X; stored as column a of Gc)
+//   P = 2:  U[i][a] = rc_i G[i][a] + sum_{r > i} LinvT[i][r] G[r][a]          (into w.X)
+// Both are (upper triangular) x (full): wave w computes the 32 x 32 block (w >> 1, w & 1) as 2 x 2
+// tiles of v_mfma_f64_16x16x4, from its block row's diagonal on; the second row tile skips the four
+// steps that lie left of its own diagonal.  Lane pointers advance by a constant per step and the
+// next step's reads are issued before this step's matrix instructions (a wave issues in order: with
+// index arithmetic per step the reads, the arithmetic and the matrix instructions took turns).  The
+// triangle and P = 2's diagonal are applied by selects on the left operand; rows and columns past q
+// read row / column 0 and only reach entries that are not stored.  Out of line: inlined into the
+// solver, whose registers are all taken, its 70 registers were spilled around every call.
+template <int P>
+static __device__ __noinline__ void sdp_wg4_tri_mm(const SdpWork w, lds_f64* Gc, double gam) {
+    typedef double sdp_double4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kg = lane >> 4;
+    const int q = w.q, LD = w.LD;
+    const int I0 = 2 * (wave >> 1), J0 = 2 * (wave & 1);
+    if (16 * I0 >= q || 16 * J0 >= q) return;
+    sdp_double4 acc[2][2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) acc[I][J] = (sdp_double4){0.0, 0.0, 0.0, 0.0};
+    const int kb = 16 * I0;                                  // first k position of the block row
+    int ir[2];
+    const lds_f64* pa[2];
+    const lds_f64* pb[2];
+    double dg[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) {
+        const int i = 16 * (I0 + I) + li, j = 16 * (J0 + I) + li;
+        const int ic = i < q ? i : 0, jc = j < q ? j : 0;
+        ir[I] = i;
+        pa[I] = (P == 1) ? w.S + (kb + kg) * LD + ic : w.S + ic * LD + kb + kg;
+        pb[I] = (P == 1) ? w.X + (kb + kg) * LD + jc : Gc + jc * LD + kb + kg;
+        dg[I] = (P == 2) ? w.rc[ic] : 0.0;
+    }
+    const int sa = (P == 1) ? 4 * LD : 4, sb = sa;
+    const int nfull = (q - kb) >> 2;                         // steps whose four k positions all lie inside q
+    auto left = [&](int I, int k, double x) {                // the triangle (and P = 2's diagonal) of the left operand
+        if (P == 1) return k >= ir[I] ? x : 0.0;
+        return k > ir[I] ? x : (k == ir[I] ? dg[I] : 0.0);
+    };
+    double av[2], bv[2], an[2], bn[2];
+#pragma unroll
+    for (int I = 0; I < 2; ++I) { av[I] = left(I, kb + kg, pa[I][0]); bv[I] = pb[I][0]; }
+    for (int s = 0; s < nfull; ++s) {
+        const bool more = s + 1 < nfull;
+        const int kn = kb + 4 * (s + 1) + kg;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            pa[I] += more ? sa : 0; pb[I] += more ? sb : 0;
+            an[I] = left(I, kn, pa[I][0]); bn[I] = pb[I][0];
+        }
+        // the second row tile starts at its own diagonal, four steps in
+#pragma unroll
+        for (int J = 0; J < 2; ++J) acc[0][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[J], acc[0][J], 0, 0, 0);
+        if (s >= 4) {
+#pragma unroll
+            for (int J = 0; J < 2; ++J) acc[1][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[J], acc[1][J], 0, 0, 0);
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I) { av[I] = an[I]; bv[I] = bn[I]; }
+    }
+    if ((q - kb) & 3) {
+        const int k = kb + 4 * nfull + kg;
+        const bool kin = k < q;
+        const int kc = kin ? k : 0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I) {
+            const int i = ir[I], j = 16 * (J0 + I) + li;
+            const int ic = i < q ? i : 0, jc = j < q ? j : 0;
+            const double x = (P == 1) ? w.S[kc * LD + ic] : w.S[ic * LD + kc];
+            const double y = (P == 1) ? w.X[kc * LD + jc] : Gc[jc * LD + kc];
+            av[I] = kin ? left(I, k, x) : 0.0;
+            bv[I] = kin ? y : 0.0;
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+                acc[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[I], bv[J], acc[I][J], 0, 0, 0);
+    }
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = 16 * (I0 + I) + kg + 4 * g, j = 16 * (J0 + J) + li;
+                if (i < q && j < q) {
+                    if (P == 1) Gc[j * LD + i] = acc[I][J][g] - gam * w.tv[i] * w.grad[j];
+                    else w.X[i * LD + j] = acc[I][J][g];
+                }
+            }
+}
+
 // Evaluate g, grad g and the eigen-state at pt.  Needs w.S, w.rc from sdp_factor_wide.  With
 // SDP_EVAL_WARM the previous state (U in w.X, 1/s in w.rs, gamma' p in w.wp, column sums in
 // w.sv) seeds this one: G <- G V_prev.  Leaves U in w.X and the vectors sq, sv, rp, s, rs, ip,
@@ -399,6 +497,8 @@ __device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps,
             w.grad[tid] = acc;                    // scratch: the gradient is written at the end
         }
         __syncthreads();
+        if constexpr (T == 256) sdp_wg4_tri_mm<1>(w, Gc, gam);
+        else
         for (int blk = tid; blk < qb * qb; blk += T) {
             const int rb = blk / qb, ab = blk - rb * qb;
             const int r0 = 2 * rb, a0 = 2 * ab;
@@ -450,6 +550,8 @@ __device__ double sdp_eval_wide(const SdpWork w, const lds_f64* pt, int& sweeps,
         w.rs[tid] = rs; w.ip[tid] = rs * rs; w.wp[tid] = gamp * pj;
     }
     // U = Lc^-T (G V): U[i][a] = rc_i G[i][a] + sum_{r > i} LinvT[i][r] G[r][a]
+    if constexpr (T == 256) sdp_wg4_tri_mm<2>(w, Gc, 0.0);
+    else
     for (int blk = tid; blk < qb * qb; blk += T) {
         const int ib = blk / qb, ab = blk - ib * qb;
         const int i0 = 2 * ib, a0 = 2 * ab;
